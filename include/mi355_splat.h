@@ -1,0 +1,173 @@
+/* mi355_splat.h — C-ABI of libmi355_splat.so: the gfx950 (MI355X) back end of the
+ * taichi_splatting render path (projection -> SH colour -> tile mapper -> alpha composite).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t on a HIP failure or a negative
+ *     MS_ERR_* code on an argument error; ms_last_error_string() describes the last failure.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; tensors are contiguous,
+ *     row-major; image_size is (W, H), images are (H, W, C).
+ *   - no function allocates device memory or synchronises (callers own every buffer, including
+ *     scratch: functions taking (tmp, tmp_bytes) report the required size in *tmp_bytes when
+ *     tmp == NULL and do nothing else).
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *   - dtype selects the float (MS_F32) or double (MS_F64) instantiation, the way the reference
+ *     specialises its Taichi kernels on the tensor dtype (rasterizer/function.py:126).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference/taichi_splatting).
+ */
+#ifndef MI355_SPLAT_H
+#define MI355_SPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_VERSION 100  /* 0.1.0 */
+
+enum { MS_F32 = 0, MS_F64 = 1 };
+
+enum {
+  MS_ERR_BAD_ARG = -1,      /* null pointer / negative size / unsupported enum */
+  MS_ERR_UNSUPPORTED = -2,  /* valid request with no compiled instantiation (e.g. F > 4) */
+  MS_ERR_TMP_TOO_SMALL = -3
+};
+
+/* Compile-time constants of the reference's RasterConfig (data_types.py:17-47) that the raster
+ * kernels consume at run time. */
+typedef struct ms_raster_config {
+  int32_t tile_size;               /* 8, 16 or 32 */
+  int32_t antialias;               /* gaussian_pdf_antialias instead of gaussian_pdf */
+  int32_t use_alpha_blending;      /* 0: quantile ("median") render, forward only */
+  int32_t compute_visibility;
+  int32_t compute_point_heuristic;
+  int32_t reserved;
+  double clamp_max_alpha;
+  double alpha_threshold;
+  double saturate_threshold;
+} ms_raster_config;
+
+int ms_version(void);
+const char* ms_last_error_string(void);
+
+/* ---- perspective projection ------------------------------------------------------------------
+ * ms_project_fwd replaces project_kernel (perspective/projection.py:33-81): per gaussian, packed
+ * 2D gaussian [mean2, axis2, sigma2, alpha] into out_points7[i], camera depth into out_depth[i]
+ * (0 when culled) and the in-view flag (0/1) into out_flag[i].  T_camera_world is the (4,4)
+ * row-major matrix (rows 0..2 used), projection = [fx, fy, cx, cy]; both are device pointers so
+ * that no host read-back of camera tensors is needed (the reference replicates them per point,
+ * projection.py:215-216). */
+int ms_project_fwd(const void* position, const void* log_scaling, const void* rotation,
+                   const void* alpha_logit, const void* T_camera_world, const void* projection,
+                   int image_w, int image_h, double near_plane, double far_plane,
+                   double blur_cov, double clamp_margin, double alpha_threshold,
+                   int64_t n, void* out_points7, void* out_depth, int32_t* out_flag,
+                   int dtype, void* stream);
+
+/* Compaction replacing torch.nonzero + 2 gathers (projection.py:147-150).  scan = exclusive scan
+ * of the flags (n+1 entries, ms_exclusive_scan_i32).  Writes the V visible rows: out_points7
+ * (V,7), out_depth (V), optional out_ndc_depth (V) = 1-(1/d-1/far)/(1/near-1/far)
+ * (torch_lib/projection.py:120-123, fused) and out_indexes (V) int64. */
+int ms_project_gather(const void* points7, const void* depth, const int32_t* flag,
+                      const int32_t* scan, int64_t n, double near_plane, double far_plane,
+                      void* out_points7, void* out_depth, void* out_ndc_depth,
+                      int64_t* out_indexes, int dtype, void* stream);
+
+/* ms_project_bwd replaces indexed_project_kernel.grad (projection.py:85-119,167-188): hand-derived
+ * reverse mode.  Rows indexes[i] of the N-sized outputs are WRITTEN (rows of culled gaussians are
+ * left untouched: pre-zero them); grad_camera (16 values: dT[3][4] row-major then d[fx,fy,cx,cy])
+ * is ACCUMULATED atomically and may be NULL. */
+int ms_project_bwd(const void* position, const void* log_scaling, const void* rotation,
+                   const void* alpha_logit, const void* T_camera_world, const void* projection,
+                   int image_w, int image_h, double blur_cov, double clamp_margin,
+                   const int64_t* indexes, int64_t v, const void* grad_points7,
+                   const void* grad_depth, void* grad_position, void* grad_log_scaling,
+                   void* grad_rotation, void* grad_alpha_logit, void* grad_camera,
+                   int dtype, void* stream);
+
+/* ---- spherical harmonics ---------------------------------------------------------------------
+ * evaluate_sh_at_kernel (indexed_spherical_harmonics.py:119-134): out[i,c] =
+ * clamp(sum_d Y_d(normalise(pos[idx]-cam)) * params[idx,c,d] + 0.5, 0, 1); params is (M, F, D),
+ * D = (degree+1)^2, degree in [0,3]. */
+int ms_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
+              const void* camera_pos, int64_t v, int f, int degree, void* out,
+              int dtype, void* stream);
+
+/* evaluate_sh_at_kernel.grad (indexed_spherical_harmonics.py:153-160).  grad_params (M,F,D),
+ * grad_positions (M,3) and grad_camera_pos (3) are ACCUMULATED atomically (indexes may repeat);
+ * any of them may be NULL. */
+int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
+              const void* camera_pos, int64_t v, int f, int degree, const void* grad_out,
+              void* grad_params, void* grad_positions, void* grad_camera_pos,
+              int dtype, void* stream);
+
+/* ---- tile mapper -----------------------------------------------------------------------------
+ * ms_tile_count replaces tile_overlaps_kernel (mapper/tile_mapper.py:76-86): counts[i] = number
+ * of tiles of the (image_w x image_h, already padded to the tile size) grid that pass the
+ * OBB-vs-tile test, restricted to tile rows [tile_row_begin, tile_row_end) (multi-GPU strips;
+ * pass 0 and a huge value for the whole image).  points7 is float. */
+int ms_tile_count(const float* points7, int64_t v, int image_w, int image_h, int tile_size,
+                  float alpha_threshold, int tile_row_begin, int tile_row_end,
+                  int32_t* out_counts, void* stream);
+
+/* cuda_lib.full_cumsum (cuda_lib/full_cumsum.cu:17-67): exclusive scan of n int32 into out[0..n],
+ * out[n] = total.  If total_host is not NULL it must be pinned, device-visible host memory and
+ * receives the total as well (valid after the stream is synchronised). */
+int ms_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host,
+                          void* tmp, size_t* tmp_bytes, void* stream);
+
+/* generate_sort_keys_kernel + make_sort_key (tile_mapper.py:36-66,115-146): for every passing
+ * tile writes key and value at cum[i]++.  key_bytes 8: (tile_id << 32) | float_bits(depth);
+ * key_bytes 4 (use_depth16): (tile_id << 16) | u16(clamp(depth,0,1)*65535).  value = point index.
+ * tile_id = tx + ty * (image_w / tile_size) — NOT limited to 16 bits for 8-byte keys. */
+int ms_tile_emit(const float* points7, const float* depth, const int32_t* cum, int64_t v,
+                 int image_w, int image_h, int tile_size, float alpha_threshold,
+                 int tile_row_begin, int tile_row_end, int key_bytes,
+                 void* out_keys, int32_t* out_values, void* stream);
+
+/* cuda_lib.radix_sort_pairs (cuda_lib/radix_sort_pairs.cu:8-70 = cub::DeviceRadixSort::SortPairs):
+ * stable LSD radix sort of n (key, int32 value) pairs on key bits [begin_bit, end_bit),
+ * out-of-place, inputs preserved.  key_bytes is 4 or 8 (unsigned order). */
+int ms_radix_sort_pairs(const void* keys_in, const int32_t* values_in, void* keys_out,
+                        int32_t* values_out, int64_t n, int key_bytes, int begin_bit, int end_bit,
+                        void* tmp, size_t* tmp_bytes, void* stream);
+
+/* cuda_lib.segmented_sort_pairs (cuda_lib/segmented_sort_pairs.cu:9-73): stable sort of each
+ * segment [start_offsets[s], end_offsets[s]) by int32 key, values int32. */
+int ms_segmented_sort_pairs(const int32_t* keys_in, const int32_t* values_in, int32_t* keys_out,
+                            int32_t* values_out, int64_t n, const int64_t* start_offsets,
+                            const int64_t* end_offsets, int64_t num_segments, void* stream);
+
+/* find_ranges_kernel (tile_mapper.py:93-112): out_ranges (num_tiles, 2) int32 = [first, last+1)
+ * of each tile id (= key >> tile_shift) in the sorted key list; empty tiles get [0, 0).  The
+ * function zero-fills out_ranges itself. */
+int ms_find_ranges(const void* sorted_keys, int64_t k, int key_bytes, int tile_shift,
+                   int64_t num_tiles, int32_t* out_ranges, void* stream);
+
+/* ---- rasterizer ------------------------------------------------------------------------------
+ * _forward_kernel (rasterizer/forward.py:23-135).  points7 (V,7), features (V,F), tile_ranges
+ * (T,2) int32 indexed by tile id = tx + ty * ceil(W/tile), overlap_to_point (K) int32.
+ * out_image (H,W,F), out_alpha (H,W), out_visibility (V) (pre-zeroed, used when
+ * cfg->compute_visibility) or NULL.  Only tile rows [tile_row_begin, tile_row_end) are rendered. */
+int ms_raster_fwd(const void* points7, const void* features, const int32_t* tile_ranges,
+                  const int32_t* overlap_to_point, int image_w, int image_h, int f,
+                  const ms_raster_config* cfg, void* out_image, void* out_alpha,
+                  void* out_visibility, int tile_row_begin, int tile_row_end,
+                  int dtype, void* stream);
+
+/* _backward_kernel (rasterizer/backward.py:51-224).  image = forward output, grad_image =
+ * dL/dimage.  grad_points7 (V,7), grad_features (V,F) and point_heuristic (V,2) are ACCUMULATED
+ * atomically (pre-zero them); each may be NULL to skip that output. */
+int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile_ranges,
+                  const int32_t* overlap_to_point, const void* image, const void* grad_image,
+                  int image_w, int image_h, int f, const ms_raster_config* cfg,
+                  void* grad_points7, void* grad_features, void* point_heuristic,
+                  int tile_row_begin, int tile_row_end, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_SPLAT_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of ``libmi355_splat.so`` (C-ABI declared in ``include/mi355_splat.h``).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  ``load()`` raises
+``RuntimeError`` if the shared object has not been built (``python __graft_entry__.py`` or
+``make -C taichi_splatting_amd/csrc``), and every wrapper raises if a tensor is not on a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int, c_int32, c_int64, c_double, c_float, c_void_p, c_size_t, c_char_p, POINTER
+import os
+from pathlib import Path
+import subprocess
+from typing import Optional
+
+import torch
+
+PACKAGE_DIR = Path(__file__).resolve().parent
+CSRC_DIR = PACKAGE_DIR / 'csrc'
+LIB_PATH = PACKAGE_DIR / 'libmi355_splat.so'
+
+MS_F32, MS_F64 = 0, 1
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class RasterConfigC(ctypes.Structure):
+  """``ms_raster_config`` of include/mi355_splat.h"""
+  _fields_ = [
+    ('tile_size', c_int32),
+    ('antialias', c_int32),
+    ('use_alpha_blending', c_int32),
+    ('compute_visibility', c_int32),
+    ('compute_point_heuristic', c_int32),
+    ('reserved', c_int32),
+    ('clamp_max_alpha', c_double),
+    ('alpha_threshold', c_double),
+    ('saturate_threshold', c_double),
+  ]
+
+
+# name -> (restype, argtypes); must list every function declared in include/mi355_splat.h
+SIGNATURES = {
+  'ms_version': (c_int, []),
+  'ms_last_error_string': (c_char_p, []),
+  'ms_project_fwd': (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_double] * 5 + [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+  'ms_project_gather': (c_int, [c_void_p] * 4 + [c_int64, c_double, c_double] + [c_void_p] * 4 + [c_int, c_void_p]),
+  'ms_project_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_double, c_double, c_void_p, c_int64] + [c_void_p] * 7 + [c_int, c_void_p]),
+  'ms_sh_fwd': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+  'ms_sh_bwd': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
+  'ms_tile_count': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
+  'ms_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_void_p]),
+  'ms_tile_emit': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'ms_radix_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p, POINTER(c_size_t), c_void_p]),
+  'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+  'ms_find_ranges': (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
+  'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
+  'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
+}
+
+
+def build(verbose: bool = False, jobs: Optional[int] = None) -> Path:
+  """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+  jobs = jobs or os.cpu_count() or 4
+  cmd = ['make', '-C', str(CSRC_DIR), f'-j{jobs}']
+  proc = subprocess.run(cmd, capture_output=True, text=True)
+  if proc.returncode != 0:
+    raise RuntimeError(f"building libmi355_splat.so failed:\n{proc.stdout}\n{proc.stderr}")
+  if verbose:
+    print(proc.stdout)
+  return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not LIB_PATH.exists():
+    raise RuntimeError(
+      f"{LIB_PATH} not found: the gfx950 kernel library has not been built. "
+      "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C taichi_splatting_amd/csrc`. "
+      "There is no CPU fallback for this path.")
+  lib = ctypes.CDLL(str(LIB_PATH))
+  for name, (restype, argtypes) in SIGNATURES.items():
+    fn = getattr(lib, name)   # AttributeError if the symbol is missing
+    fn.restype = restype
+    fn.argtypes = argtypes
+  _lib = lib
+  return lib
+
+
+def check(rc: int, what: str):
+  if rc != 0:
+    msg = load().ms_last_error_string().decode('utf-8', 'replace')
+    if rc == -2:
+      raise NotImplementedError(f"{what}: {msg}")
+    if rc < 0:
+      raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+  """Device pointer of a contiguous tensor (None -> NULL)."""
+  if t is None:
+    return None
+  assert t.is_contiguous(), "tensor must be contiguous"
+  return t.data_ptr()
+
+
+def require_gpu(*tensors: torch.Tensor):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise RuntimeError(
+        "taichi_splatting_amd runs on MI355X (gfx950) only: got a tensor on "
+        f"{t.device}. There is no CPU fallback; move the inputs to the GPU.")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+  if dtype == torch.float32:
+    return MS_F32
+  if dtype == torch.float64:
+    return MS_F64
+  raise TypeError(f"unsupported dtype {dtype}: float32 or float64 expected")
+
+
+def current_stream(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def raster_config_c(config) -> RasterConfigC:
+  return RasterConfigC(
+    tile_size=config.tile_size, antialias=int(config.antialias),
+    use_alpha_blending=int(config.use_alpha_blending),
+    compute_visibility=int(config.compute_visibility),
+    compute_point_heuristic=int(config.compute_point_heuristic), reserved=0,
+    clamp_max_alpha=config.clamp_max_alpha, alpha_threshold=config.alpha_threshold,
+    saturate_threshold=config.saturate_threshold)

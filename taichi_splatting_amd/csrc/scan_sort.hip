@@ -1,0 +1,400 @@
+// scan_sort.hip — integer primitives of the tile mapper, hand-written for wave64:
+//   * exclusive prefix sum of int32 (replaces cub::DeviceScan::ExclusiveSum, full_cumsum.cu:17-47)
+//   * stable LSD radix sort of (key, int32 value) pairs, 8-bit digits, u32/u64 keys
+//     (replaces cub::DeviceRadixSort::SortPairs, radix_sort_pairs.cu:8-70)
+//   * segmented pair sort (cub::DeviceSegmentedSort::SortPairs, segmented_sort_pairs.cu:9-73;
+//     not on the render path — kept for API parity)
+//
+// Radix pass = upsweep (per-block digit histogram) -> scan of the digit-major histogram ->
+// downsweep (stable in-block ranking with wave64 ballots, then scatter).  Block item order is
+// wave-major, round-major, lane-minor, so loads are fully coalesced and stability only needs
+// (earlier waves) + (earlier rounds of this wave) + (lower lanes of this round).
+#include "common.h"
+
+namespace ms {
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+// exclusive scan of one int per thread across a 256-thread block; returns the exclusive prefix,
+// *block_total receives the block sum (valid in all threads).
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds /*>= 4 ints*/, int* block_total) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  int wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    const int s = lds[w];
+    if (w < wave) wave_off += s;
+    total += s;
+  }
+  __syncthreads();
+  *block_total = total;
+  return wave_off + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ block_sums) {
+  __shared__ int lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int64_t i = base + k;
+    if (i < n) s += in[i];
+  }
+  int total;
+  block_exclusive_scan(s, lds, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of block_sums in place; writes the grand total
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_spine_kernel(int32_t* __restrict__ block_sums, int64_t num_blocks, int32_t* __restrict__ total_out,
+                  int32_t* __restrict__ total_host) {
+  __shared__ int lds[4];
+  int carry = 0;
+  for (int64_t base = 0; base < num_blocks; base += SCAN_THREADS) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < num_blocks ? block_sums[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, &total);
+    if (i < num_blocks) block_sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (total_host) *total_host = carry;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_downsweep_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ block_offsets,
+                      int32_t* __restrict__ out) {
+  __shared__ int lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int vals[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int64_t i = base + k;
+    vals[k] = i < n ? in[i] : 0;
+    s += vals[k];
+  }
+  int total;
+  int prefix = block_exclusive_scan(s, lds, &total) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int64_t i = base + k;
+    if (i < n) out[i] = prefix;
+    prefix += vals[k];
+  }
+}
+
+static size_t scan_tmp_bytes(int64_t n) { return align_up((size_t)div_up(n > 0 ? n : 1, SCAN_TILE) * sizeof(int32_t), 256); }
+
+// out has n + 1 entries (out[n] = total).  in and out may NOT alias unless identical ranges are
+// intended (in == out is allowed: every block reads its tile before writing it).
+static int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp,
+                              hipStream_t s) {
+  const int64_t blocks = div_up(n, SCAN_TILE);
+  int32_t* block_sums = (int32_t*)tmp;
+  scan_block_sums_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums);
+  scan_spine_kernel<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(block_sums, blocks, out + n, total_host);
+  scan_downsweep_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ROUNDS = 16;                          // items per thread
+constexpr int RS_WAVE_ITEMS = RS_ROUNDS * 64;          // 1024
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;        // 4096 items per block
+constexpr int RS_RADIX = 256;
+
+template <typename KeyT>
+__device__ __forceinline__ unsigned key_digit(KeyT k, int shift, unsigned mask) {
+  return (unsigned)(k >> shift) & mask;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_upsweep_kernel(const KeyT* __restrict__ keys, int64_t n, int shift, unsigned mask,
+                     int32_t* __restrict__ hist, int64_t num_blocks) {
+  __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
+  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS + lane;
+#pragma unroll 4
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const int64_t i = base + j * 64;
+    if (i < n) atomicAdd(&cnt[wave][key_digit(keys[i], shift, mask)], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
+    unsigned t = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) t += cnt[w][d];
+    hist[(int64_t)d * num_blocks + blockIdx.x] = (int32_t)t;
+  }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
+                       unsigned mask, const int32_t* __restrict__ hist_scanned, int64_t num_blocks) {
+  __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
+  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS + lane;
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+  KeyT k[RS_ROUNDS];
+  int32_t v[RS_ROUNDS];
+  unsigned rank[RS_ROUNDS];   // rank of the item among equal digits of this wave
+
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const int64_t i = base + j * 64;
+    const bool valid = i < n;
+    k[j] = valid ? keys_in[i] : (KeyT)0;
+    v[j] = valid ? vals_in[i] : 0;
+  }
+
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const int64_t i = base + j * 64;
+    const bool valid = i < n;
+    const unsigned d = key_digit(k[j], shift, mask);
+    // match-any over the 8 digit bits: peers = lanes holding the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const unsigned below = (unsigned)__popcll(peers & lanes_below);
+    unsigned prev = 0;
+    if (valid) {
+      prev = cnt[wave][d];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (valid && below == 0) cnt[wave][d] = prev + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    rank[j] = prev + below;
+  }
+  __syncthreads();
+
+  // digit bases: global start of this block's run of digit d + counts of earlier waves
+  for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
+    unsigned run = (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) {
+      const unsigned c = cnt[w][d];
+      cnt[w][d] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const int64_t i = base + j * 64;
+    if (i < n) {
+      const unsigned d = key_digit(k[j], shift, mask);
+      const int64_t pos = (int64_t)cnt[wave][d] + rank[j];
+      keys_out[pos] = k[j];
+      vals_out[pos] = v[j];
+    }
+  }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256)
+copy_pairs_kernel(const KeyT* __restrict__ ki, const int32_t* __restrict__ vi, KeyT* __restrict__ ko,
+                  int32_t* __restrict__ vo, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { ko[i] = ki[i]; vo[i] = vi[i]; }
+}
+
+struct SortTmp {
+  size_t hist_off, scan_off, keys_off, vals_off, total;
+};
+
+static SortTmp sort_tmp_layout(int64_t n, int key_bytes) {
+  const int64_t blocks = div_up(n > 0 ? n : 1, RS_TILE);
+  SortTmp t;
+  size_t off = 0;
+  t.hist_off = off; off += align_up((size_t)(RS_RADIX * blocks + 1) * sizeof(int32_t), 256);
+  t.scan_off = off; off += scan_tmp_bytes(RS_RADIX * blocks);
+  t.keys_off = off; off += align_up((size_t)n * key_bytes, 256);
+  t.vals_off = off; off += align_up((size_t)n * sizeof(int32_t), 256);
+  t.total = off;
+  return t;
+}
+
+template <typename KeyT>
+static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, KeyT* keys_out,
+                                 int32_t* vals_out, int64_t n, int begin_bit, int end_bit, char* tmp,
+                                 hipStream_t s) {
+  const int64_t blocks = div_up(n, RS_TILE);
+  const SortTmp lay = sort_tmp_layout(n, sizeof(KeyT));
+  int32_t* hist = (int32_t*)(tmp + lay.hist_off);
+  void* scan_tmp = tmp + lay.scan_off;
+  KeyT* keys_alt = (KeyT*)(tmp + lay.keys_off);
+  int32_t* vals_alt = (int32_t*)(tmp + lay.vals_off);
+
+  const int passes = (end_bit - begin_bit + 7) / 8;
+  if (passes == 0) {
+    copy_pairs_kernel<KeyT><<<dim3((unsigned)div_up(n, 256)), dim3(256), 0, s>>>(keys_in, vals_in, keys_out, vals_out, n);
+    return 0;
+  }
+  const KeyT* src_k = keys_in;
+  const int32_t* src_v = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = begin_bit + 8 * p;
+    const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+    const unsigned mask = (1u << bits) - 1u;
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    KeyT* dst_k = to_out ? keys_out : keys_alt;
+    int32_t* dst_v = to_out ? vals_out : vals_alt;
+
+    radix_upsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(src_k, n, shift, mask, hist, blocks);
+    exclusive_scan_i32(hist, RS_RADIX * blocks, hist, nullptr, scan_tmp, s);
+    radix_downsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(
+        src_k, src_v, dst_k, dst_v, n, shift, mask, hist, blocks);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// segmented sort (API parity only): one block per segment, stable rank sort
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+segmented_rank_sort_kernel(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                           int32_t* __restrict__ keys_out, int32_t* __restrict__ vals_out,
+                           const int64_t* __restrict__ starts, const int64_t* __restrict__ ends) {
+  const int64_t b = starts[blockIdx.x], e = ends[blockIdx.x];
+  for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+    const int32_t k = keys_in[i];
+    int64_t r = 0;
+    for (int64_t j = b; j < e; ++j) {
+      const int32_t kj = keys_in[j];
+      r += (kj < k) || (kj == k && j < i);
+    }
+    keys_out[b + r] = k;
+    vals_out[b + r] = vals_in[i];
+  }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(256)
+find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, int shift, int64_t num_tiles,
+                   int32_t* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int64_t tile = (int64_t)(keys[i] >> shift);
+  const int64_t next = (i + 1 < k) ? (int64_t)(keys[i + 1] >> shift) : -1;
+  if (i == 0 && tile < num_tiles) ranges[tile * 2 + 0] = 0;
+  if (tile != next) {
+    if (tile < num_tiles) ranges[tile * 2 + 1] = (int32_t)(i + 1);
+    if (next >= 0 && next < num_tiles) ranges[next * 2 + 0] = (int32_t)(i + 1);
+  }
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host,
+                                     void* tmp, size_t* tmp_bytes, void* stream) {
+  MS_CHECK_ARG(n >= 0, "n < 0");
+  MS_CHECK_ARG(tmp_bytes != nullptr, "tmp_bytes is null");
+  const size_t need = scan_tmp_bytes(n);
+  if (tmp == nullptr) { *tmp_bytes = need; return 0; }
+  if (*tmp_bytes < need) { set_error("ms_exclusive_scan_i32: tmp too small (%zu < %zu)", *tmp_bytes, need); return MS_ERR_TMP_TOO_SMALL; }
+  MS_CHECK_ARG(out != nullptr, "out is null");
+  MS_CHECK_ARG(n == 0 || in != nullptr, "in is null");
+  if (n == 0) {
+    MS_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), (hipStream_t)stream));
+    if (total_host) *total_host = 0;
+    return 0;
+  }
+  exclusive_scan_i32(in, n, out, total_host, tmp, (hipStream_t)stream);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_radix_sort_pairs(const void* keys_in, const int32_t* values_in, void* keys_out,
+                                   int32_t* values_out, int64_t n, int key_bytes, int begin_bit,
+                                   int end_bit, void* tmp, size_t* tmp_bytes, void* stream) {
+  MS_CHECK_ARG(n >= 0, "n < 0");
+  MS_CHECK_ARG(key_bytes == 4 || key_bytes == 8, "key_bytes must be 4 or 8");
+  MS_CHECK_ARG(begin_bit >= 0 && end_bit >= begin_bit && end_bit <= key_bytes * 8, "bad bit range");
+  MS_CHECK_ARG(tmp_bytes != nullptr, "tmp_bytes is null");
+  const size_t need = sort_tmp_layout(n, key_bytes).total;
+  if (tmp == nullptr) { *tmp_bytes = need; return 0; }
+  if (*tmp_bytes < need) { set_error("ms_radix_sort_pairs: tmp too small (%zu < %zu)", *tmp_bytes, need); return MS_ERR_TMP_TOO_SMALL; }
+  if (n == 0) return 0;
+  MS_CHECK_ARG(keys_in && values_in && keys_out && values_out, "null pointer");
+  if (key_bytes == 4)
+    radix_sort_pairs_impl<uint32_t>((const uint32_t*)keys_in, values_in, (uint32_t*)keys_out, values_out, n, begin_bit, end_bit, (char*)tmp, (hipStream_t)stream);
+  else
+    radix_sort_pairs_impl<uint64_t>((const uint64_t*)keys_in, values_in, (uint64_t*)keys_out, values_out, n, begin_bit, end_bit, (char*)tmp, (hipStream_t)stream);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_segmented_sort_pairs(const int32_t* keys_in, const int32_t* values_in, int32_t* keys_out,
+                                       int32_t* values_out, int64_t n, const int64_t* start_offsets,
+                                       const int64_t* end_offsets, int64_t num_segments, void* stream) {
+  MS_CHECK_ARG(n >= 0 && num_segments >= 0, "negative size");
+  if (n == 0 || num_segments == 0) return 0;
+  MS_CHECK_ARG(keys_in && values_in && keys_out && values_out && start_offsets && end_offsets, "null pointer");
+  // elements outside every segment are copied through unchanged (CUB leaves them unspecified)
+  copy_pairs_kernel<int32_t><<<dim3((unsigned)div_up(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      keys_in, values_in, keys_out, values_out, n);
+  segmented_rank_sort_kernel<<<dim3((unsigned)num_segments), dim3(256), 0, (hipStream_t)stream>>>(
+      keys_in, values_in, keys_out, values_out, start_offsets, end_offsets);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_find_ranges(const void* sorted_keys, int64_t k, int key_bytes, int tile_shift,
+                              int64_t num_tiles, int32_t* out_ranges, void* stream) {
+  MS_CHECK_ARG(k >= 0 && num_tiles >= 0, "negative size");
+  MS_CHECK_ARG(key_bytes == 4 || key_bytes == 8, "key_bytes must be 4 or 8");
+  MS_CHECK_ARG(out_ranges != nullptr || num_tiles == 0, "out_ranges is null");
+  if (num_tiles > 0)
+    MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), (hipStream_t)stream));
+  if (k == 0) return 0;
+  MS_CHECK_ARG(sorted_keys != nullptr, "sorted_keys is null");
+  const dim3 block(256), grid((unsigned)div_up(k, 256));
+  if (key_bytes == 4)
+    find_ranges_kernel<uint32_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint32_t*)sorted_keys, k, tile_shift, num_tiles, out_ranges);
+  else
+    find_ranges_kernel<uint64_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint64_t*)sorted_keys, k, tile_shift, num_tiles, out_ranges);
+  MS_CHECK_LAUNCH();
+  return 0;
+}

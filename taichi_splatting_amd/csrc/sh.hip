@@ -1,0 +1,169 @@
+// sh.hip — view-dependent colour from real spherical harmonics (degree 0..3), forward + backward.
+//
+// One thread per visible gaussian; params rows are (F, D) contiguous (D = (deg+1)^2), i.e. 192 B
+// per gaussian for RGB degree 3: a pure HBM stream, gathered through the int64 index list.
+#include "common.h"
+
+namespace ms {
+
+constexpr int SH_MAX_F = 4;
+
+template <typename T, int DEG>
+__global__ void __launch_bounds__(256)
+sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
+              const int64_t* __restrict__ indexes, const T* __restrict__ cam_pos, int64_t v, int f,
+              T* __restrict__ out) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v) return;
+  const int64_t idx = indexes[i];
+
+  const T dx = positions[idx * 3 + 0] - cam_pos[0];
+  const T dy = positions[idx * 3 + 1] - cam_pos[1];
+  const T dz = positions[idx * 3 + 2] - cam_pos[2];
+  const T len = t_sqrt(dx * dx + dy * dy + dz * dz);
+  T Y[D];
+  sh_basis<T, DEG>(dx / len, dy / len, dz / len, Y);
+
+  const T* p = params + idx * (int64_t)f * D;
+  for (int c = 0; c < f; ++c) {
+    T acc = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc += Y[d] * p[c * D + d];
+    out[i * f + c] = t_clamp(acc + T(0.5), T(0), T(1));
+  }
+}
+
+template <typename T, int DEG>
+__global__ void __launch_bounds__(256)
+sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
+              const int64_t* __restrict__ indexes, const T* __restrict__ cam_pos, int64_t v, int f,
+              const T* __restrict__ g_out, T* __restrict__ g_params, T* __restrict__ g_positions,
+              T* __restrict__ g_cam) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+  T dcam[3] = {T(0), T(0), T(0)};
+  if (i < v) {
+    const int64_t idx = indexes[i];
+    const T dx = positions[idx * 3 + 0] - cam_pos[0];
+    const T dy = positions[idx * 3 + 1] - cam_pos[1];
+    const T dz = positions[idx * 3 + 2] - cam_pos[2];
+    const T len = t_sqrt(dx * dx + dy * dy + dz * dz);
+    const T x = dx / len, y = dy / len, z = dz / len;
+    T Y[D];
+    sh_basis<T, DEG>(x, y, z, Y);
+
+    const T* p = params + idx * (int64_t)f * D;
+    T coef[D];   // sum_c g_c m_c P[c, d]: the weights of grad Y_d in d_dir
+#pragma unroll
+    for (int d = 0; d < D; ++d) coef[d] = T(0);
+
+    for (int c = 0; c < f; ++c) {
+      T acc = T(0);
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc += Y[d] * p[c * D + d];
+      const T pre = acc + T(0.5);
+      // clamp passes the gradient where 0 <= pre <= 1 (torch.clamp convention)
+      const T g = (pre >= T(0) && pre <= T(1)) ? g_out[i * f + c] : T(0);
+      if (g_params) {
+        T* gp = g_params + (idx * (int64_t)f + c) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) atomic_add_noret(gp + d, g * Y[d]);
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) coef[d] += g * p[c * D + d];
+    }
+
+    if (g_positions || g_cam) {
+      T gd[3];
+      sh_basis_grad_dot<T, DEG>(x, y, z, coef, gd);
+      // dir = d / |d|: dp = (I - dir dir^T) gd / |d|
+      const T dot = x * gd[0] + y * gd[1] + z * gd[2];
+      const T gx = (gd[0] - x * dot) / len, gy = (gd[1] - y * dot) / len, gz = (gd[2] - z * dot) / len;
+      if (g_positions) {
+        atomic_add_noret(g_positions + idx * 3 + 0, gx);
+        atomic_add_noret(g_positions + idx * 3 + 1, gy);
+        atomic_add_noret(g_positions + idx * 3 + 2, gz);
+      }
+      dcam[0] = -gx; dcam[1] = -gy; dcam[2] = -gz;
+    }
+  }
+  if (g_cam) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const T s = wave_sum_to_lane63(dcam[k]);
+      if (lane_id() == 63 && s != T(0)) atomic_add_noret(g_cam + k, s);
+    }
+  }
+}
+
+template <typename T>
+static int launch_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
+                         const void* cam, int64_t v, int f, int degree, void* out, hipStream_t s) {
+  const dim3 block(256), grid((unsigned)div_up(v, 256));
+#define MS_SH_FWD(DEG) \
+  sh_fwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, indexes, (const T*)cam, v, f, (T*)out)
+  switch (degree) {
+    case 0: MS_SH_FWD(0); break;
+    case 1: MS_SH_FWD(1); break;
+    case 2: MS_SH_FWD(2); break;
+    default: MS_SH_FWD(3); break;
+  }
+#undef MS_SH_FWD
+  return 0;
+}
+
+template <typename T>
+static int launch_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
+                         const void* cam, int64_t v, int f, int degree, const void* g_out,
+                         void* g_params, void* g_positions, void* g_cam, hipStream_t s) {
+  const dim3 block(256), grid((unsigned)div_up(v, 256));
+#define MS_SH_BWD(DEG)                                                                              \
+  sh_bwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, indexes,      \
+                                                (const T*)cam, v, f, (const T*)g_out, (T*)g_params, \
+                                                (T*)g_positions, (T*)g_cam)
+  switch (degree) {
+    case 0: MS_SH_BWD(0); break;
+    case 1: MS_SH_BWD(1); break;
+    case 2: MS_SH_BWD(2); break;
+    default: MS_SH_BWD(3); break;
+  }
+#undef MS_SH_BWD
+  return 0;
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
+                         const void* camera_pos, int64_t v, int f, int degree, void* out, int dtype,
+                         void* stream) {
+  MS_CHECK_ARG(v >= 0, "v < 0");
+  MS_CHECK_ARG(degree >= 0 && degree <= 3, "degree must be in [0, 3]");
+  MS_CHECK_ARG(f >= 1, "f < 1");
+  MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
+  if (v == 0) return 0;
+  MS_CHECK_ARG(params && positions && indexes && camera_pos && out, "null pointer");
+  if (dtype == MS_F32) launch_sh_fwd<float>(params, positions, indexes, camera_pos, v, f, degree, out, (hipStream_t)stream);
+  else launch_sh_fwd<double>(params, positions, indexes, camera_pos, v, f, degree, out, (hipStream_t)stream);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
+                         const void* camera_pos, int64_t v, int f, int degree, const void* grad_out,
+                         void* grad_params, void* grad_positions, void* grad_camera_pos, int dtype,
+                         void* stream) {
+  MS_CHECK_ARG(v >= 0, "v < 0");
+  MS_CHECK_ARG(degree >= 0 && degree <= 3, "degree must be in [0, 3]");
+  MS_CHECK_ARG(f >= 1, "f < 1");
+  MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
+  if (v == 0) return 0;
+  MS_CHECK_ARG(params && positions && indexes && camera_pos && grad_out, "null pointer");
+  if (dtype == MS_F32) launch_sh_bwd<float>(params, positions, indexes, camera_pos, v, f, degree, grad_out, grad_params, grad_positions, grad_camera_pos, (hipStream_t)stream);
+  else launch_sh_bwd<double>(params, positions, indexes, camera_pos, v, f, degree, grad_out, grad_params, grad_positions, grad_camera_pos, (hipStream_t)stream);
+  MS_CHECK_LAUNCH();
+  return 0;
+}

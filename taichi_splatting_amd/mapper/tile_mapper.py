@@ -1,0 +1,121 @@
+"""Tile mapper: which gaussians touch which screen tiles, depth sorted per tile.
+
+Same interface as reference ``mapper/tile_mapper.py:204-225`` (``map_to_tiles``) and ``:20-24``
+(``pad_to_tile``).  Stages (csrc/mapper.hip, csrc/scan_sort.hip):
+OBB-vs-tile overlap count -> exclusive scan (one host read of the total K) -> key emission
+``tile_id << 32 | float_bits(depth)`` -> stable radix sort over bits [0, 32 + ceil(log2 T)) ->
+per-tile ranges.  Unlike the reference (``tile_mapper.py:177-178``) the tile id is not limited to
+16 bits, so 2048x2048 @ tile 8 and 4096x4096 @ tile 16 (65536 tiles) work.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from numbers import Integral
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+from ..data_types import RasterConfig
+
+
+def pad_to_tile(image_size: Tuple[Integral, Integral], tile_size: int):
+  def pad(x):
+    return int(math.ceil(x / tile_size) * tile_size)
+  return tuple(pad(x) for x in image_size)
+
+
+def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
+                       image_size: Tuple[Integral, Integral], config: RasterConfig,
+                       use_depth16: bool = False,
+                       tile_rows: Optional[Tuple[int, int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+  """``map_to_tiles`` restricted to tile rows [tile_rows[0], tile_rows[1]) (multi-GPU strips).
+
+  ``tile_ranges`` is still indexed by the global tile id; tiles outside the strip are empty.
+  """
+  lib = _lib.load()
+  _lib.require_gpu(gaussians, depth)
+  assert gaussians.ndim == 2 and gaussians.shape[1] == 7, f"gaussians must be Nx7 got {gaussians.shape}"
+  assert depth.ndim == 2 and depth.shape[1] == 1, f"depths must be Nx1, got {depth.shape}"
+  assert gaussians.shape[0] == depth.shape[0], f"size mismatch {gaussians.shape} {depth.shape}"
+
+  tile_size = config.tile_size
+  w_pad, h_pad = pad_to_tile(image_size, tile_size)
+  tile_shape = (h_pad // tile_size, w_pad // tile_size)
+  num_tiles = tile_shape[0] * tile_shape[1]
+  if use_depth16:
+    assert num_tiles <= 65536, \
+      f"tile dimensions {tile_shape} for image size {(w_pad, h_pad)} exceed the 16 bit tile id of use_depth16 keys"
+  assert num_tiles < (1 << 31), "too many tiles"
+
+  row_begin, row_end = (0, tile_shape[0]) if tile_rows is None else tile_rows
+  device = gaussians.device
+  stream = _lib.current_stream(device)
+
+  with torch.no_grad():
+    # the overlap test runs in float32 like the reference (Gaussian2D from taichi_lib.f32)
+    points = gaussians.detach().to(torch.float32).contiguous()
+    depths = depth.detach().to(torch.float32).reshape(-1).contiguous()
+    v = points.shape[0]
+
+    tile_ranges = torch.zeros((*tile_shape, 2), dtype=torch.int32, device=device)
+    if v == 0:
+      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
+
+    counts = torch.empty((v,), dtype=torch.int32, device=device)
+    _lib.check(lib.ms_tile_count(points.data_ptr(), v, w_pad, h_pad, tile_size, config.alpha_threshold,
+                                 row_begin, row_end, counts.data_ptr(), stream), "map_to_tiles")
+
+    cum = torch.empty((v + 1,), dtype=torch.int32, device=device)
+    nbytes = ctypes.c_size_t(0)
+    _lib.check(lib.ms_exclusive_scan_i32(None, v, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
+    tmp = torch.empty((max(nbytes.value, 1),), dtype=torch.uint8, device=device)
+    _lib.check(lib.ms_exclusive_scan_i32(counts.data_ptr(), v, cum.data_ptr(), None, tmp.data_ptr(),
+                                         ctypes.byref(nbytes), stream), "map_to_tiles")
+    total = int(cum[v].item())   # the one host sync of the mapper: K sizes the key buffers
+
+    if total == 0:
+      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
+
+    key_bytes = 4 if use_depth16 else 8
+    key_dtype = torch.int32 if use_depth16 else torch.int64
+    keys = torch.empty((total,), dtype=key_dtype, device=device)
+    values = torch.empty((total,), dtype=torch.int32, device=device)
+    _lib.check(lib.ms_tile_emit(points.data_ptr(), depths.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
+                                tile_size, config.alpha_threshold, row_begin, row_end, key_bytes,
+                                keys.data_ptr(), values.data_ptr(), stream), "map_to_tiles")
+
+    tile_bits = max(1, (num_tiles - 1).bit_length())
+    depth_bits = 16 if use_depth16 else 32
+    end_bit = min(depth_bits + tile_bits, key_bytes * 8)
+
+    keys_sorted = torch.empty_like(keys)
+    overlap_to_point = torch.empty_like(values)
+    _lib.check(lib.ms_radix_sort_pairs(None, None, None, None, total, key_bytes, 0, end_bit, None,
+                                       ctypes.byref(nbytes), stream), "map_to_tiles")
+    tmp = torch.empty((max(nbytes.value, 1),), dtype=torch.uint8, device=device)
+    _lib.check(lib.ms_radix_sort_pairs(keys.data_ptr(), values.data_ptr(), keys_sorted.data_ptr(),
+                                       overlap_to_point.data_ptr(), total, key_bytes, 0, end_bit,
+                                       tmp.data_ptr(), ctypes.byref(nbytes), stream), "map_to_tiles")
+
+    _lib.check(lib.ms_find_ranges(keys_sorted.data_ptr(), total, key_bytes, depth_bits, num_tiles,
+                                  tile_ranges.data_ptr(), stream), "map_to_tiles")
+    return overlap_to_point, tile_ranges
+
+
+def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple[Integral, Integral],
+                 config: RasterConfig, use_depth16: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Maps gaussians to tiles, sorted by depth (front to back).
+
+  Parameters:
+    gaussians: (N, 7) packed 2D gaussians
+    depth: (N, 1) depths (sorted as float32, must be >= 0)
+    image_size: (width, height)
+    config: RasterConfig (tile_size, alpha_threshold)
+
+  Returns:
+    overlap_to_point: (K,) int32, overlap index -> point index
+    tile_ranges: (TH, TW, 2) int32, tile -> [start, end) range of overlap indices
+  """
+  return map_to_tiles_strip(gaussians, depth, image_size, config, use_depth16=use_depth16)

@@ -1,0 +1,158 @@
+"""Pins for the rasterizer / tile-mapper oracle, for which the reference holds no golden data
+(SURVEY.md 8c): hand-computable known answers, gradcheck (the reference's own rasterizer test,
+tests/test_rasterizer.py:62-90), literal-backward vs autograd, the visibility identity
+(tests/test_visibility.py:34-64) and brute-force mapper invariants."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mapper as omap, raster as orast
+from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+from taichi_splatting_amd.testing import random_2d_gaussians
+
+
+def one_tile(n, ts=8):
+  return torch.arange(n, dtype=torch.int32), torch.tensor([[0, n]], dtype=torch.int32)
+
+
+def test_kat_single_isotropic_splat():
+  # one isotropic splat centred on pixel centre (3.5, 4.5): image = min(alpha, .99) * f there,
+  # alpha * exp(-1/(2 sigma^2)) * f at the 4-neighbours
+  sigma, alpha = 1.5, 0.6
+  p = torch.tensor([[3.5, 4.5, 1.0, 0.0, sigma, sigma, alpha]], dtype=torch.float64)
+  f = torch.tensor([[0.2, 0.5, 1.0]], dtype=torch.float64)
+  o2p, ranges = one_tile(1)
+  img, a, vis = orast.forward(p, f, ranges, o2p, (8, 8), orast.Cfg(tile_size=8))
+  assert torch.allclose(img[4, 3], alpha * f[0])
+  nb = alpha * math.exp(-1 / (2 * sigma ** 2))
+  for (y, x) in ((4, 2), (4, 4), (3, 3), (5, 3)):
+    assert torch.allclose(img[y, x], nb * f[0])
+    assert abs(a[y, x].item() - nb) < 1e-14
+  assert abs(vis[0].item() - a.sum().item()) < 1e-12
+
+
+def test_kat_two_stacked_splats_and_clamp_threshold():
+  # C = f1 a1 + f2 a2 (1 - a1); a1 clamps to 0.99; contributions below 1/255 are dropped
+  p = torch.tensor([[2.5, 2.5, 1.0, 0.0, 50.0, 50.0, 1.0],
+                    [2.5, 2.5, 0.0, 1.0, 50.0, 50.0, 0.5],
+                    [2.5, 2.5, 1.0, 0.0, 50.0, 50.0, 0.003]], dtype=torch.float64)
+  f = torch.tensor([[1.0], [10.0], [1000.0]], dtype=torch.float64)
+  o2p, ranges = one_tile(3)
+  img, a, _ = orast.forward(p, f, ranges, o2p, (8, 8), orast.Cfg(tile_size=8))
+  a1 = 0.99
+  a2 = 0.5 * math.exp(0.0)
+  assert abs(img[2, 2, 0].item() - (1.0 * a1 + 10.0 * a2 * (1 - a1))) < 1e-12
+  assert abs(a[2, 2].item() - (a1 + a2 * (1 - a1))) < 1e-12
+
+
+def _random_tile_inputs(seed, antialias=False):
+  torch.manual_seed(seed)
+  n = int(torch.randint(1, 50, (1,)))
+  ch = int(torch.randint(1, 4, (1,)))
+  g = random_2d_gaussians(n, (8, 8), num_channels=ch, scale_factor=1.0, alpha_range=(0.2, 0.8))
+  return project_gaussians2d(g).double(), g.feature.double(), n
+
+
+@pytest.mark.parametrize('antialias', [False, True])
+def test_oracle_gradcheck_single_tile(antialias):
+  # protocol of the reference's tests/test_rasterizer.py:30-90 (8x8 image, one tile, 1-49 splats)
+  cfg = orast.Cfg(tile_size=8, antialias=antialias)
+  for seed in range(3):
+    p, f, n = _random_tile_inputs(seed, antialias)
+    o2p, ranges = one_tile(n)
+
+    def render(p_, f_):
+      return orast.rasterize_autograd(p_, f_, ranges, o2p, (8, 8), cfg)
+    torch.autograd.gradcheck(render, (p.clone().requires_grad_(True), f.clone().requires_grad_(True)),
+                             eps=1e-6, atol=1e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize('antialias', [False, True])
+def test_literal_backward_matches_autograd(antialias):
+  cfg = orast.Cfg(tile_size=8, antialias=antialias)
+  for seed in range(10):
+    p, f, n = _random_tile_inputs(seed)
+    o2p, ranges = one_tile(n)
+    img, _, _ = orast.forward(p, f, ranges, o2p, (8, 8), cfg)
+    G = torch.randn_like(img)
+    gp, gf, _ = orast.backward(p, f, ranges, o2p, img, G, (8, 8), cfg)
+    pp, ff = p.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    img2 = orast.rasterize_autograd(pp, ff, ranges, o2p, (8, 8), cfg)
+    assert torch.allclose(img2, img, atol=1e-13)
+    (img2 * G).sum().backward()
+    # the literal backward skips saturated pixels (W >= 0.9999): allow that much slack
+    assert torch.allclose(gp, pp.grad, atol=2e-3 * max(1.0, pp.grad.abs().max().item()), rtol=1e-3)
+    assert torch.allclose(gf, ff.grad, atol=2e-4, rtol=1e-3)
+
+
+def test_visibility_identity_and_mapper_invariants():
+  torch.manual_seed(3)
+  size = (320, 200)
+  g = random_2d_gaussians(3000, size, scale_factor=0.2, alpha_range=(0.2, 1.0))
+  p = project_gaussians2d(g).double()
+  depth = torch.clamp(g.depths, 0, 1).float()
+  o2p, ranges, counts = omap.map_to_tiles(p.numpy(), depth.numpy(), size, 16)
+  K = o2p.shape[0]
+  assert counts.sum() == K
+  flat = ranges.reshape(-1, 2)
+  nonempty = flat[flat[:, 1] > flat[:, 0]]
+  # ranges partition [0, K)
+  assert nonempty[:, 0].min() == 0 and nonempty[:, 1].max() == K
+  order = np.argsort(nonempty[:, 0])
+  assert np.all(nonempty[order][1:, 0] == nonempty[order][:-1, 1])
+  # depth non-decreasing inside each range, ties by ascending point index
+  d = depth.numpy().reshape(-1)
+  for s, e in nonempty:
+    dd, ii = d[o2p[s:e]], o2p[s:e]
+    assert np.all(np.diff(dd) >= 0)
+    ties = np.diff(dd) == 0
+    assert np.all(np.diff(ii)[ties] > 0)
+
+  cfg = orast.Cfg(compute_visibility=True)
+  o2p_t, ranges_t = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  f = g.feature.double()
+  img, a, vis = orast.forward(p, f, ranges_t, o2p_t, size, cfg)
+  gp, gf, _ = orast.backward(p, f, ranges_t, o2p_t, img, torch.ones_like(img), size, cfg)
+  # with dL/dimage = 1 the feature gradient is the visibility (tests/test_visibility.py:58-64),
+  # up to the pixels the backward pass skips once saturated
+  assert torch.allclose(gf[:, 0], vis, rtol=1e-5, atol=2e-3)
+
+
+def test_mapper_membership_is_bruteforce_sat():
+  # every (point, tile) membership agrees with an independent float64 SAT evaluation, except
+  # pairs that are numerically on the decision boundary
+  torch.manual_seed(5)
+  size = (100, 70)
+  g = random_2d_gaussians(200, size, scale_factor=1.5, alpha_range=(0.05, 1.0))
+  p = project_gaussians2d(g).numpy().astype(np.float32)
+  thr = 1 / 255.
+  pid, tx, ty = omap.overlaps(p, size, 16, thr)
+  got = set(zip(pid.tolist(), tx.tolist(), ty.tolist()))
+  w_pad, h_pad = omap.pad_to_tile(size, 16)
+  want = set()
+  p64 = p.astype(np.float64)
+  for i in range(p.shape[0]):
+    mean, a1, sig, alpha = p64[i, 0:2], p64[i, 2:4], p64[i, 4:6], p64[i, 6]
+    if alpha <= thr:
+      continue
+    gs = math.sqrt(2 * math.log(alpha / thr))
+    sc = sig * gs
+    a2 = np.array([-a1[1], a1[0]])
+    ext = np.sqrt((a1 * sc[0]) ** 2 + (a2 * sc[1]) ** 2)
+    lo = np.maximum(np.floor((mean - ext) / 16), 0).astype(int)
+    hi = np.ceil((mean + ext) / 16).astype(int)
+    hi = np.minimum(np.maximum(hi, lo + 1), [w_pad // 16, h_pad // 16])
+    for x in range(lo[0], hi[0]):
+      for y in range(lo[1], hi[1]):
+        corners = np.array([[x, y], [x + 1, y], [x + 1, y + 1], [x, y + 1]], dtype=np.float64) * 16 - mean
+        ok = True
+        for ax, s in ((a1, sc[0]), (a2, sc[1])):
+          pr = corners @ ax / s
+          if pr.min() > 1 or pr.max() < -1:
+            ok = False
+        if ok:
+          want.add((i, x, y))
+  border = omap.borderline_pairs(p, size, 16, thr)
+  assert (got ^ want) <= border, sorted(got ^ want)[:5]
