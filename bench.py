@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""Headline benchmark: forward+backward of ``render_gaussians`` on a synthetic random-gaussian scene.
+
+    python bench.py [--gpus N --steps K --warmup W] [--n 6000000 --size 2048 --tile 16 --sh-degree 3]
+
+A step = one full frame: project -> SH colour -> tile map (count/scan/emit/sort/ranges) -> raster
+forward -> loss = image.sum() -> raster backward -> SH backward -> projection backward, on inputs
+already resident in HBM.  Default workload = BASELINE.json configs[3] ("config D": 6M gaussians,
+2048x2048, SH degree 3, tile 16), the configuration the metric is quoted on.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the SAME frame is sharded by screen-tile strips with the
+per-gaussian 2D-boundary gradients all-reduced over RCCL -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (metric, roofline of the dominant kernel, CPU-oracle baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+  sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse_args():
+  p = argparse.ArgumentParser()
+  p.add_argument('--gpus', type=int, default=1)
+  p.add_argument('--steps', type=int, default=20)
+  p.add_argument('--warmup', type=int, default=3)
+  p.add_argument('--n', type=int, default=6_000_000)
+  p.add_argument('--size', type=int, default=2048)
+  p.add_argument('--height', type=int, default=None)
+  p.add_argument('--tile', type=int, default=16)
+  p.add_argument('--sh-degree', type=int, default=3)
+  p.add_argument('--seed', type=int, default=0)
+  p.add_argument('--no-cpu-baseline', action='store_true')
+  p.add_argument('--no-stages', action='store_true')
+  p.add_argument('--forward-only', action='store_true')
+  return p.parse_args()
+
+
+def make_scene(args, device):
+  from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+  torch.manual_seed(args.seed)
+  size = (args.size, args.height or args.size)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(args.n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9), margin=0.0)
+  d = (args.sh_degree + 1) ** 2
+  g = g.replace(feature=(torch.rand(args.n, 3, d) - 0.5) * 0.5)
+  return g.to(device), cam.to(device=device)
+
+
+def algorithmic_bytes(N, V, K, P, T, F, D, passes):
+  """compulsory HBM bytes per frame, fp32, each stream counted once."""
+  b = {}
+  b['project_fwd'] = 44 * N + 40 * V
+  b['sh_fwd'] = (4 * F * D + 12 + 8) * V + 4 * F * V
+  b['tile_count'] = 28 * V + 4 * V
+  b['scan'] = 8 * V
+  b['tile_emit'] = 36 * V + 12 * K
+  b['sort'] = passes * 24 * K
+  b['ranges'] = 8 * K + 8 * T
+  b['raster_fwd'] = (4 + 28 + 4 * F) * K + 4 * (F + 1) * P
+  b['raster_bwd'] = (4 + 28 + 4 * F) * K + 8 * F * P + (28 + 4 * F) * K
+  b['sh_bwd'] = (4 * F * D + 12 + 8 + 4 * F) * V + 4 * F * D * V
+  b['project_bwd'] = (44 + 32 + 8) * V + 44 * V
+  return b
+
+
+def cuda_time_ms(fn, iters=5, warmup=1):
+  for _ in range(warmup):
+    fn()
+  torch.cuda.synchronize()
+  start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  start.record()
+  for _ in range(iters):
+    fn()
+  end.record()
+  torch.cuda.synchronize()
+  return start.elapsed_time(end) / iters
+
+
+def stage_breakdown(g, cam, cfg, use_sh):
+  """Per-stage GPU time (HIP events on the stream the kernels are launched on) + V, K."""
+  from taichi_splatting_amd import _lib
+  from taichi_splatting_amd.perspective.projection import project_to_image
+  from taichi_splatting_amd.spherical_harmonics import evaluate_sh_at
+  from taichi_splatting_amd.mapper.tile_mapper import map_to_tiles
+  from taichi_splatting_amd.rasterizer.function import rasterize_with_tiles
+  from taichi_splatting_amd.rendering import ndc_depth
+
+  lib = _lib.load()
+  out = {}
+  with torch.no_grad():
+    out['project_fwd'] = cuda_time_ms(lambda: project_to_image(g, cam, cfg))
+    g2d, depths, idx = project_to_image(g, cam, cfg)
+    cam_pos = cam.camera_position
+    if use_sh:
+      out['sh_fwd'] = cuda_time_ms(lambda: evaluate_sh_at(g.feature, g.position, idx, cam_pos))
+      feats = evaluate_sh_at(g.feature, g.position, idx, cam_pos)
+    else:
+      feats = g.feature[idx]
+    ndc = ndc_depth(depths, cam.near_plane, cam.far_plane)
+    out['map_to_tiles'] = cuda_time_ms(lambda: map_to_tiles(g2d, ndc, cam.image_size, cfg))
+    o2p, ranges = map_to_tiles(g2d, ndc, cam.image_size, cfg)
+    ranges2 = ranges.view(-1, 2)
+    out['raster_fwd'] = cuda_time_ms(lambda: rasterize_with_tiles(g2d, feats, o2p, ranges2, cam.image_size, cfg))
+    image = rasterize_with_tiles(g2d, feats, o2p, ranges2, cam.image_size, cfg).image
+
+    # the dominant kernel, timed alone through the C-ABI
+    grad_image = torch.ones_like(image)
+    gp, gf = torch.zeros_like(g2d), torch.zeros_like(feats)
+    cfg_c = _lib.raster_config_c(cfg)
+    w, h = cam.image_size
+    stream = _lib.current_stream(g2d.device)
+    tiles_high = (h + cfg.tile_size - 1) // cfg.tile_size
+
+    def bwd():
+      _lib.check(lib.ms_raster_bwd(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
+                                   image.data_ptr(), grad_image.data_ptr(), w, h, feats.shape[1], cfg_c,
+                                   gp.data_ptr(), gf.data_ptr(), None, 0, tiles_high, 0, stream), "bench raster_bwd")
+    out['raster_bwd'] = cuda_time_ms(bwd, iters=10, warmup=2)
+  return out, int(idx.shape[0]), int(o2p.shape[0])
+
+
+def cpu_baseline(args):
+  """The CPU oracle (torch restatement of the reference path; the reference has no CPU rasterizer)
+  timed on a bounded sample of the same workload family: 20k gaussians, 256x256, fwd+bwd."""
+  import numpy as np
+  from oracle import mapper as omap, projection as oproj, raster as orast, sh as osh
+  from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+  from taichi_splatting_amd import RasterConfig
+
+  n, size = 20000, (256, 256)
+  torch.manual_seed(0)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  d = (args.sh_degree + 1) ** 2
+  feat = ((torch.rand(n, 3, d) - 0.5) * 0.5)
+  cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  torch.set_num_threads(os.cpu_count() or 1)
+
+  t0 = time.perf_counter()
+  leaves = [t.clone().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, feat)]
+  pos, ls, rot, al, ft = leaves
+  points, depths, idx = oproj.apply(pos, ls, rot, al, cam.T_camera_world, cam.projection, size, cam.depth_range,
+                                    cfg.blur_cov, cfg.clamp_margin, cfg.alpha_threshold)
+  feats = osh.evaluate_sh_at(ft, pos.detach(), idx, torch.inverse(cam.T_camera_world)[0:3, 3])
+  ndc = oproj.ndc_depth(depths.detach(), *cam.depth_range)
+  o2p, ranges, _ = omap.map_to_tiles(points.detach().numpy(), ndc.numpy(), size, cfg.tile_size, cfg.alpha_threshold)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  image, alpha, _ = orast.forward(points.detach(), feats.detach(), ranges, o2p, size, cfg)
+  gp, gf, _ = orast.backward(points.detach(), feats.detach(), ranges, o2p, image, torch.ones_like(image), size, cfg)
+  torch.autograd.backward([points, feats], [gp, gf])
+  dt = time.perf_counter() - t0
+  return {"value": round(n / dt / 1e6, 5), "unit": "Msplats/s", "cores": torch.get_num_threads(), "kind": "port",
+          "sample": f"oracle (torch {torch.__version__} CPU restatement) fwd+bwd, {n} gaussians, {size[0]}x{size[1]}, "
+                    f"SH deg {args.sh_degree}, tile {args.tile}, K={int(o2p.shape[0])}, {dt:.2f} s"}
+
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  distributed = world > 1
+  if distributed:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl')
+  device = torch.device('cuda', local_rank)
+  torch.cuda.set_device(device)
+
+  from taichi_splatting_amd import RasterConfig, render_gaussians, _lib
+  from taichi_splatting_amd.distributed import render_strip_step
+  _lib.load()
+
+  cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  g, cam = make_scene(args, device)
+  use_sh = True
+  g.requires_grad_(not args.forward_only)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+
+  def step():
+    for t in leaves:
+      t.grad = None
+    if distributed:
+      render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
+                        backward=not args.forward_only)
+    elif args.forward_only:
+      with torch.no_grad():
+        render_gaussians(g, cam, cfg, use_sh=use_sh)
+    else:
+      r = render_gaussians(g, cam, cfg, use_sh=use_sh)
+      r.image.sum().backward()
+
+  for _ in range(args.warmup):
+    step()
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if distributed:
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  ms_per_step = elapsed / args.steps * 1e3
+  value = args.n / (ms_per_step * 1e-3) / 1e6
+
+  result = {
+    "metric": "fwd+bwd Msplats/s" if not args.forward_only else "fwd Msplats/s",
+    "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    "dtype": "f32", "data": "synthetic",
+    "config": {"workload": f"config D: {args.n} random 3D gaussians, {cam.image_size[0]}x{cam.image_size[1]}, "
+                           f"SH deg {args.sh_degree}, tile {args.tile}, "
+                           f"{'fwd+bwd' if not args.forward_only else 'fwd'} (render_gaussians, loss=image.sum())",
+               "n_gaussians": args.n, "image_size": list(cam.image_size), "tile_size": args.tile,
+               "sh_degree": args.sh_degree,
+               "parallelism": f"tile-strips x{world} + all-reduce of 2D-boundary grads" if distributed else "single GPU"},
+  }
+
+  if rank == 0 and not args.no_stages:
+    g.requires_grad_(False)
+    stages, V, K = stage_breakdown(g, cam, cfg, use_sh)
+    w, h = cam.image_size
+    P = w * h
+    T = ((w + args.tile - 1) // args.tile) * ((h + args.tile - 1) // args.tile)
+    F, D = 3, (args.sh_degree + 1) ** 2
+    passes = (32 + max(1, (T - 1).bit_length()) + 7) // 8
+    alg = algorithmic_bytes(args.n, V, K, P, T, F, D, passes)
+    dom = 'raster_bwd'
+    achieved = alg[dom] / (stages[dom] * 1e-3) / 1e9
+    result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_kernel<float,3,%d>" % args.tile,
+                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                          "kernel_ms": round(stages[dom], 4), "algorithmic_bytes": alg[dom],
+                          "note": "alpha-composite passes are VALU/LDS bound at these K*tile^2 (SURVEY 8d)"}
+    frame_bytes = sum(alg.values())
+    result["frame"] = {"V": V, "K": K, "K_per_N": round(K / args.n, 3), "K_per_tile": round(K / T, 1),
+                       "algorithmic_bytes": frame_bytes,
+                       "hbm_frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "stage_ms": {k: round(v, 4) for k, v in stages.items()}}
+
+  if rank == 0 and not args.no_cpu_baseline:
+    result["cpu_baseline"] = cpu_baseline(args)
+
+  if rank == 0:
+    print(json.dumps(result))
+  if distributed:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,116 @@
+"""-m gpu: projection and SH kernels (through the C-ABI) vs the oracle and the reference fixtures.
+Tolerances: f64 = the reference's own (torch.allclose defaults, tests/test_projection.py:38-74;
+atol 1e-5 for SH, tests/util.py:62-63); f32 = 1e-4 relative except the ill-conditioned axis."""
+import pytest
+import torch
+
+from oracle import projection as oproj, sh as osh
+from taichi_splatting_amd import evaluate_sh_at, RasterConfig, Gaussians3D
+from taichi_splatting_amd.perspective import projection as hip_proj, project_to_image
+from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+from .conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _eval_with_grad(f, *args):
+  args = [a.detach().clone().requires_grad_(True) for a in args]
+  out = f(*args)
+  outs = out if isinstance(out, tuple) else (out,)
+  loss = sum(o.mean() for o in outs if o.is_floating_point())
+  loss.backward()
+  return [o.detach() for o in outs], [a.grad if a.grad is not None else torch.zeros_like(a) for a in args]
+
+
+@pytest.mark.parametrize('seed', range(5))
+def test_projection_fixture_f64(seed):
+  fix = load_golden(f'projection_seed{seed}.pt')
+  ref = fix['f64']
+  inputs = [t.to(DEV) for t in ref['inputs']]
+  outs, grads = _eval_with_grad(
+    lambda *a: hip_proj.apply(*a, fix['image_size'], fix['depth_range'], blur_cov=fix['blur_cov']), *inputs)
+  assert torch.equal(outs[2].cpu(), ref['indexes'])
+  assert outs[2].dtype == torch.int64
+  assert torch.allclose(outs[0].cpu(), ref['points'])
+  assert torch.allclose(outs[1].cpu(), ref['depth'])
+  for name, g, gr in zip(('position', 'log_scaling', 'rotation', 'alpha_logit', 'T_camera_world', 'projection'),
+                         grads, ref['grads']):
+    assert g.shape == gr.shape, name
+    assert torch.allclose(g.cpu(), gr, rtol=1e-5, atol=1e-9), (name, (g.cpu() - gr).abs().max())
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_projection_random_vs_oracle(seed):
+  # protocol of tests/test_projection.py:22-96 (random camera, 1..10000 points, margin .5)
+  torch.manual_seed(seed)
+  camera = random_camera()
+  n = int(torch.randint(1, 10000, (1,)))
+  g = random_3d_gaussians(n=n, camera_params=camera, margin=0.5, scale_factor=0.1)
+  for dtype in (torch.float64, torch.float32):
+    inputs = [t.to(dtype) for t in g.shape_tensors()] + [camera.T_camera_world.to(dtype), camera.projection.to(dtype)]
+    f_o = lambda *a: oproj.apply(*a, camera.image_size, camera.depth_range, blur_cov=0.3)
+    f_h = lambda *a: hip_proj.apply(*a, camera.image_size, camera.depth_range, blur_cov=0.3)
+    o_out, o_grad = _eval_with_grad(f_o, *inputs)
+    h_out, h_grad = _eval_with_grad(f_h, *[t.to(DEV) for t in inputs])
+    if dtype == torch.float64:
+      assert torch.equal(h_out[2].cpu(), o_out[2])
+      assert torch.allclose(h_out[0].cpu(), o_out[0])
+      assert torch.allclose(h_out[1].cpu(), o_out[1])
+      for g_h, g_o in zip(h_grad, o_grad):
+        assert torch.allclose(g_h.cpu(), g_o, rtol=1e-5, atol=1e-9), (g_h.cpu() - g_o).abs().max()
+    else:
+      # f32 culling decisions may flip for gaussians numerically on the frustum boundary
+      a, b = set(h_out[2].cpu().tolist()), set(o_out[2].tolist())
+      assert len(a ^ b) <= max(1, n // 2000), (len(a ^ b), n)
+      common = sorted(a & b)
+      if len(a ^ b) == 0:
+        assert torch.allclose(h_out[0].cpu()[:, [0, 1, 4, 5, 6]], o_out[0][:, [0, 1, 4, 5, 6]], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(h_out[1].cpu(), o_out[1], rtol=1e-4, atol=1e-5)
+
+
+def test_projection_empty_and_all_culled():
+  cam = random_camera(image_size=(64, 48))
+  cfg = RasterConfig()
+  g = Gaussians3D(position=torch.zeros(0, 3), log_scaling=torch.zeros(0, 3), rotation=torch.zeros(0, 4),
+                  alpha_logit=torch.zeros(0, 1), feature=torch.zeros(0, 3), batch_size=(0,)).to(DEV)
+  p, d, idx = project_to_image(g, cam.to(device=DEV), cfg)
+  assert p.shape == (0, 7) and d.shape == (0, 1) and idx.shape == (0,)
+  # behind the camera: nothing visible
+  T = cam.T_camera_world
+  behind = (torch.inverse(T) @ torch.tensor([0., 0., -5., 1.]))[:3]
+  g = Gaussians3D(position=behind.repeat(10, 1), log_scaling=torch.zeros(10, 3),
+                  rotation=torch.tensor([[0., 0, 0, 1]]).repeat(10, 1), alpha_logit=torch.zeros(10, 1),
+                  feature=torch.zeros(10, 3), batch_size=(10,)).to(DEV)
+  p, d, idx = project_to_image(g, cam.to(device=DEV), cfg)
+  assert p.shape == (0, 7) and idx.shape == (0,)
+
+
+@pytest.mark.parametrize('degree', range(4))
+def test_sh_fixture_f64(degree):
+  fix = load_golden(f'sh_deg{degree}.pt')
+  idx = fix['indexes'].to(DEV)
+  outs, grads = _eval_with_grad(lambda p, x, c: evaluate_sh_at(p, x, idx, c),
+                                fix['params'].to(DEV), fix['points'].to(DEV), fix['camera_pos'].to(DEV))
+  assert torch.allclose(outs[0].cpu(), fix['out'], atol=1e-12)
+  for g, gr in zip(grads, fix['grads']):
+    assert torch.allclose(g.cpu(), gr, atol=1e-10), (g.cpu() - gr).abs().max()
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_sh_random_f32_vs_oracle(seed):
+  # protocol of tests/test_spherical_harmonics.py:16-45 (f32, atol 1e-5, repeated indexes)
+  torch.random.manual_seed(seed)
+  dimension = int(torch.randint(1, 4, (1,)))
+  degree = int(torch.randint(0, 4, (1,)))
+  n = int(torch.randint(1, 102, (1,)))
+  params = torch.rand(n, dimension, (degree + 1) ** 2)
+  points = torch.randn(n, 3)
+  camera_pos = torch.randn(3)
+  indexes = torch.randint(0, n, (max(n // 2, 1),))
+  o_out, o_grad = _eval_with_grad(lambda p, x, c: osh.evaluate_sh_at(p, x, indexes, c), params, points, camera_pos)
+  h_out, h_grad = _eval_with_grad(lambda p, x, c: evaluate_sh_at(p, x, indexes.to(DEV), c),
+                                  params.to(DEV), points.to(DEV), camera_pos.to(DEV))
+  assert torch.allclose(h_out[0].cpu(), o_out[0], atol=1e-5)
+  for g_h, g_o in zip(h_grad, o_grad):
+    assert torch.allclose(g_h.cpu(), g_o, atol=1e-5), (g_h.cpu() - g_o).abs().max()

@@ -1,0 +1,195 @@
+"""-m gpu: the raster forward/backward kernels (through the C-ABI) vs the oracle.
+
+Tolerances: float64 1e-9 (same algorithm, different summation order); float32 1e-4 absolute on
+pixels and 1e-4 relative-to-scale on gradients (BASELINE.json north_star: "pixels/grads within
+1e-4"), excluding pixels where some splat sits numerically on the alpha_threshold gate."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mapper as omap, raster as orast
+from taichi_splatting_amd import RasterConfig, rasterize, rasterize_with_tiles, map_to_tiles
+from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+from taichi_splatting_amd.testing import random_2d_gaussians
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def scene(n, size, seed, scale=1.0, alpha=(0.1, 0.9), channels=3, tile_size=16, depth_range=(0., 1.)):
+  torch.manual_seed(seed)
+  g = random_2d_gaussians(n, size, num_channels=channels, scale_factor=scale, alpha_range=alpha, depth_range=depth_range)
+  p = project_gaussians2d(g)
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, tile_size)
+  return p, g.feature, g.depths, torch.from_numpy(o2p), torch.from_numpy(ranges)
+
+
+def cfg_for(tile_size, **kw):
+  return RasterConfig(tile_size=tile_size, pixel_stride=(1, 1) if tile_size == 8 else (2, 2), **kw)
+
+
+@pytest.mark.parametrize('tile_size', [8, 16, 32])
+@pytest.mark.parametrize('antialias', [False, True])
+def test_forward_backward_f64(tile_size, antialias):
+  size = (150, 100)    # not a multiple of any tile size: exercises out-of-bounds pixels
+  cfg = cfg_for(tile_size, antialias=antialias, compute_visibility=True, compute_point_heuristic=True)
+  p, f, d, o2p, ranges = scene(3000, size, seed=tile_size, scale=1.5, tile_size=tile_size)
+  p, f = p.double(), f.double()
+  img_o, a_o, vis_o = orast.forward(p, f, ranges, o2p, size, cfg)
+
+  pg, fg = p.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  assert out.image.shape == (100, 150, 3) and out.image_weight.shape == (100, 150)
+  assert torch.allclose(out.image.cpu(), img_o, atol=1e-9)
+  assert torch.allclose(out.image_weight.cpu(), a_o, atol=1e-9)
+  assert torch.allclose(out.visibility.cpu(), vis_o, atol=1e-8)
+
+  torch.manual_seed(0)
+  G = torch.randn_like(img_o)
+  gp_o, gf_o, h_o = orast.backward(p, f, ranges, o2p, img_o, G, size, cfg)
+  (out.image * G.to(DEV)).sum().backward()
+  scale = max(1.0, gp_o.abs().max().item())
+  assert torch.allclose(pg.grad.cpu(), gp_o, atol=1e-8 * scale, rtol=1e-7)
+  assert torch.allclose(fg.grad.cpu(), gf_o, atol=1e-9, rtol=1e-7)
+  assert torch.allclose(out.point_heuristic.cpu(), h_o, atol=1e-7 * max(1.0, h_o.abs().max().item()), rtol=1e-6)
+
+
+@pytest.mark.parametrize('tile_size', [8, 16, 32])
+def test_forward_backward_f32_config_a(tile_size):
+  # BASELINE config A shape: 10k random 2D gaussians, 256x256
+  size = (256, 256)
+  cfg = cfg_for(tile_size)
+  p, f, d, o2p, ranges = scene(10000, size, seed=0, tile_size=tile_size)
+  img_o, a_o, _, border = orast.forward(p.double(), f.double(), ranges, o2p, size, cfg, return_borderline=True)
+  pg, fg = p.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  ok = ~border
+  assert ok.float().mean() > 0.999
+  err = (out.image.cpu().double() - img_o).abs().max(-1).values
+  assert err[ok].max() < 1e-4, err[ok].max()
+  assert (out.image_weight.cpu().double() - a_o).abs()[ok].max() < 1e-4
+  assert err.max() < 2e-2        # a flipped gate changes a pixel by at most ~alpha_threshold * |f|
+
+  G = torch.ones_like(img_o)
+  gp_o, gf_o, _ = orast.backward(p.double(), f.double(), ranges, o2p, img_o, G, size, cfg)
+  out.image.sum().backward()
+  for got, want in ((pg.grad, gp_o), (fg.grad, gf_o)):
+    scale = want.abs().max().item()
+    assert (got.cpu().double() - want).abs().max() < 1e-4 * max(1.0, scale) + 5e-3, \
+      ((got.cpu().double() - want).abs().max(), scale)
+    # and tightly in the bulk
+    rel = (got.cpu().double() - want).abs() / (want.abs() + 1e-2 * scale)
+    assert rel.quantile(0.999) < 1e-3
+
+
+@pytest.mark.parametrize('antialias', [False, True])
+def test_gradcheck_single_tile(antialias):
+  # the reference's own rasterizer test: tests/test_rasterizer.py:30-90 (f64, eps 1e-6, 8x8 image,
+  # one tile, 1..49 gaussians, 1..3 channels, overlap_to_point = arange, tile_ranges = [[0, n]])
+  cfg = RasterConfig(tile_size=8, pixel_stride=(1, 1), antialias=antialias, use_alpha_blending=True)
+  torch.manual_seed(0)
+  seeds = torch.randint(0, 1000, (20,))
+  for seed in seeds:
+    torch.random.manual_seed(int(seed))
+    n = int(torch.randint(1, 50, (1,)))
+    channels = int(torch.randint(1, 4, (1,)))
+    g = random_2d_gaussians(n, (8, 8), num_channels=channels, scale_factor=1.0, alpha_range=(0.2, 0.8))
+    g2 = project_gaussians2d(g).to(device=DEV, dtype=torch.float64)
+    colors = g.feature.to(device=DEV, dtype=torch.float64)
+    o2p = torch.arange(0, n, device=DEV, dtype=torch.int32)
+    ranges = torch.tensor([[0, n]], device=DEV, dtype=torch.int32)
+
+    def render(mean, axis, sigma, alpha, colors):
+      packed = torch.cat([mean, axis, sigma, alpha], dim=-1)
+      return rasterize_with_tiles(packed, colors, overlap_to_point=o2p, tile_overlap_ranges=ranges,
+                                  image_size=(8, 8), config=cfg).image
+    inputs = (g2[:, 0:2].clone().requires_grad_(True), g2[:, 2:4].clone().requires_grad_(True),
+              g2[:, 4:6].clone().requires_grad_(True), g2[:, 6:7].clone().requires_grad_(True),
+              colors.clone().requires_grad_(True))
+    torch.autograd.gradcheck(render, inputs, eps=1e-6, check_grad_dtypes=True, check_undefined_grad=True,
+                             nondet_tol=1e-10)
+
+
+def test_visibility_identity():
+  # tests/test_visibility.py:34-64: with dL/dimage = 1, feature.grad[:, 0] == visibility (f64,
+  # 320x200, default tile 16 / stride 2x2), through map_to_tiles + forward + backward
+  np.random.seed(0)
+  torch.manual_seed(0)
+  size = (320, 200)
+  cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+  for i in range(10):
+    n = np.random.randint(1, 10000)
+    g = random_2d_gaussians(n, size, scale_factor=0.2, alpha_range=(0.2, 1.0)).to(DEV).to(dtype=torch.float64)
+    g.feature.requires_grad_(True)
+    raster = rasterize(gaussians2d=project_gaussians2d(g), depth=torch.clamp(g.depths, 0, 1).to(torch.float32),
+                       features=g.feature, image_size=size, config=cfg)
+    raster.image.sum().backward()
+    assert torch.allclose(g.feature.grad[:, 0], raster.visibility)
+    assert raster.point_heuristic.shape == (n, 2)
+
+
+@pytest.mark.parametrize('channels', [1, 2, 4, 5, 9])
+def test_feature_widths(channels):
+  size = (96, 64)
+  cfg = RasterConfig()
+  p, f, d, o2p, ranges = scene(1500, size, seed=channels, channels=channels)
+  p, f = p.double(), f.double()
+  img_o, a_o, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  G = torch.randn_like(img_o)
+  gp_o, gf_o, _ = orast.backward(p, f, ranges, o2p, img_o, G, size, cfg)
+  pg, fg = p.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  assert torch.allclose(out.image.cpu(), img_o, atol=1e-9)
+  (out.image * G.to(DEV)).sum().backward()
+  assert torch.allclose(pg.grad.cpu(), gp_o, atol=1e-8 * max(1, gp_o.abs().max().item()))
+  assert torch.allclose(fg.grad.cpu(), gf_o, atol=1e-9)
+
+
+def test_quantile_render_no_blending():
+  # use_alpha_blending=False + saturate_threshold = median_threshold (renderer.py:77-82)
+  size = (128, 96)
+  cfg = RasterConfig(use_alpha_blending=False, saturate_threshold=0.25)
+  p, f, d, o2p, ranges = scene(4000, size, seed=7, scale=2.0, alpha=(0.3, 0.9), channels=1)
+  p, f = p.double(), f.double()
+  img_o, a_o, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  out = rasterize_with_tiles(p.to(DEV), f.to(DEV), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  assert torch.equal(out.image_weight.cpu(), a_o)
+  mism = (out.image.cpu() - img_o).abs().max(-1).values > 1e-12
+  assert mism.float().mean() < 1e-3      # only pixels numerically on the quantile threshold may differ
+
+
+def test_many_batches_per_tile_and_early_exit():
+  # > 256 splats per tile (several LDS batches) with opaque splats: exercises the corrected
+  # in-group loop bound and the backward saturation early-out
+  size = (64, 64)
+  cfg = RasterConfig()
+  p, f, d, o2p, ranges = scene(6000, size, seed=11, scale=6.0, alpha=(0.6, 1.0))
+  assert int((ranges[..., 1] - ranges[..., 0]).max()) > 600
+  p, f = p.double(), f.double()
+  img_o, a_o, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  G = torch.randn_like(img_o)
+  gp_o, gf_o, _ = orast.backward(p, f, ranges, o2p, img_o, G, size, cfg)
+  pg, fg = p.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  assert torch.allclose(out.image.cpu(), img_o, atol=1e-9)
+  (out.image * G.to(DEV)).sum().backward()
+  assert torch.allclose(pg.grad.cpu(), gp_o, atol=1e-7 * max(1, gp_o.abs().max().item()))
+  assert torch.allclose(fg.grad.cpu(), gf_o, atol=1e-8)
+
+
+def test_empty_inputs_and_requires_grad_subsets():
+  cfg = RasterConfig()
+  size = (40, 24)
+  out = rasterize(torch.zeros((0, 7), device=DEV), torch.zeros((0, 1), device=DEV), torch.zeros((0, 3), device=DEV), size, cfg)
+  assert out.image.shape == (24, 40, 3) and float(out.image.abs().sum()) == 0 and float(out.image_weight.abs().sum()) == 0
+  p, f, d, o2p, ranges = scene(300, size, seed=2)
+  pg = p.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, f.to(DEV), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  out.image.sum().backward()
+  assert pg.grad is not None and pg.grad.abs().sum() > 0
+  fg = f.to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(p.to(DEV), fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  out.image.sum().backward()
+  assert fg.grad is not None and fg.grad.abs().sum() > 0
