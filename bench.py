@@ -144,7 +144,13 @@ def cpu_baseline(args):
   d = (args.sh_degree + 1) ** 2
   feat = ((torch.rand(n, 3, d) - 0.5) * 0.5)
   cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
-  torch.set_num_threads(os.cpu_count() or 1)
+  # the GPU box reports the host's full core count; tiny per-tile torch ops collapse when spread
+  # over that many threads, so the baseline uses at most 8 threads of the cores we may run on
+  try:
+    avail = len(os.sched_getaffinity(0))
+  except AttributeError:
+    avail = os.cpu_count() or 1
+  torch.set_num_threads(max(1, min(8, avail)))
 
   t0 = time.perf_counter()
   leaves = [t.clone().requires_grad_(True) for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, feat)]
@@ -162,6 +168,11 @@ def cpu_baseline(args):
   return {"value": round(n / dt / 1e6, 5), "unit": "Msplats/s", "cores": torch.get_num_threads(), "kind": "port",
           "sample": f"oracle (torch {torch.__version__} CPU restatement) fwd+bwd, {n} gaussians, {size[0]}x{size[1]}, "
                     f"SH deg {args.sh_degree}, tile {args.tile}, K={int(o2p.shape[0])}, {dt:.2f} s"}
+
+
+def log(msg):
+  if int(os.environ.get('RANK', '0')) == 0:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -184,7 +195,9 @@ def main():
   _lib.load()
 
   cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  log(f"building scene n={args.n} size={args.size}")
   g, cam = make_scene(args, device)
+  log("scene on device")
   use_sh = True
   g.requires_grad_(not args.forward_only)
   leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
@@ -202,8 +215,10 @@ def main():
       r = render_gaussians(g, cam, cfg, use_sh=use_sh)
       r.image.sum().backward()
 
-  for _ in range(args.warmup):
+  for i in range(args.warmup):
     step()
+    torch.cuda.synchronize()
+    log(f"warmup step {i} done")
 
   def barrier():
     if distributed:
@@ -222,6 +237,7 @@ def main():
     elapsed = float(t.item())
 
   ms_per_step = elapsed / args.steps * 1e3
+  log(f"timed {args.steps} steps: {ms_per_step:.3f} ms/step")
   value = args.n / (ms_per_step * 1e-3) / 1e6
 
   result = {
@@ -240,6 +256,7 @@ def main():
   if rank == 0 and not args.no_stages:
     g.requires_grad_(False)
     stages, V, K = stage_breakdown(g, cam, cfg, use_sh)
+    log(f"stages {stages} V={V} K={K}")
     w, h = cam.image_size
     P = w * h
     T = ((w + args.tile - 1) // args.tile) * ((h + args.tile - 1) // args.tile)

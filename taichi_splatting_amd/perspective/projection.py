@@ -53,10 +53,11 @@ def _project_forward(position, log_scaling, rotation, alpha_logit, T_camera_worl
   depth = torch.empty((v, 1), dtype=dtype, device=device)
   ndc = torch.empty((v, 1), dtype=dtype, device=device) if with_ndc else None
   indexes = torch.empty((v,), dtype=torch.int64, device=device)
-  _lib.check(lib.ms_project_gather(points_full.data_ptr(), depth_full.data_ptr(), flags.data_ptr(),
-                                   scan.data_ptr(), n, float(depth_range[0]), float(depth_range[1]),
-                                   points.data_ptr(), depth.data_ptr(), _lib.ptr(ndc), indexes.data_ptr(),
-                                   code, stream), "project_to_image")
+  if v > 0:
+    _lib.check(lib.ms_project_gather(points_full.data_ptr(), depth_full.data_ptr(), flags.data_ptr(),
+                                     scan.data_ptr(), n, float(depth_range[0]), float(depth_range[1]),
+                                     points.data_ptr(), depth.data_ptr(), _lib.ptr(ndc), indexes.data_ptr(),
+                                     code, stream), "project_to_image")
   return points, depth, indexes, ndc
 
 
