@@ -98,11 +98,15 @@ int ms_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
 
 /* evaluate_sh_at_kernel.grad (indexed_spherical_harmonics.py:153-160).  grad_params (M,F,D),
  * grad_positions (M,3) and grad_camera_pos (3) are ACCUMULATED atomically (indexes may repeat);
- * any of them may be NULL. */
+ * any of them may be NULL.  out = the saved forward output (V,F) or NULL: with it, and when only
+ * grad_params is requested (the renderer detaches positions, renderer.py:53), a streaming kernel
+ * with coalesced row writes is used; unique_indexes != 0 additionally promises that indexes holds
+ * no repeats (true for the projection's compaction list), so rows are WRITTEN with plain stores
+ * (rows not listed stay untouched: pre-zero grad_params). */
 int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
-              const void* camera_pos, int64_t v, int f, int degree, const void* grad_out,
-              void* grad_params, void* grad_positions, void* grad_camera_pos,
-              int dtype, void* stream);
+              const void* camera_pos, int64_t v, int f, int degree, const void* out,
+              const void* grad_out, void* grad_params, void* grad_positions,
+              void* grad_camera_pos, int unique_indexes, int dtype, void* stream);
 
 /* ---- tile mapper -----------------------------------------------------------------------------
  * ms_tile_count replaces tile_overlaps_kernel (mapper/tile_mapper.py:76-86): counts[i] = number

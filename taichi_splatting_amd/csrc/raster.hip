@@ -27,20 +27,25 @@ template <typename T> struct RasterParams {
   T clamp_max_alpha, alpha_threshold, saturate_threshold;
 };
 
-// staged splat: AoS so the wave-uniform reads in the hot loop are a few wide broadcast LDS reads
+// staged splat: AoS so the wave-uniform reads in the hot loop are a few wide broadcast LDS reads.
+// The pdf is evaluated in the splat's normalised frame:  X = dx*A + dy*B,  Y = dx*C + dy*D  with
+// A = ax/sx, B = ay/sx, C = -ay/sy, D = ax/sy  (so X = d.axis/sigma_x, Y = d.perp(axis)/sigma_y,
+// taichi_lib/generic.py:311-317), g = exp(-(X^2 + Y^2)/2).
 template <typename T, int F> struct alignas(16) Splat {
-  T mx, my, ax, ay;       // mean, axis
-  T isx, isy, sx, sy;     // 1/sigma and sigma
+  T mx, my, A, B;
+  T C, D, isx, isy;
   T alpha;
   T f[F];
+  T ax, ay, sx, sy;       // only read by the antialiased pdf
 };
-
 template <typename T> struct CullBox { T cx, cy, ex, ey; };
 
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
-__device__ __forceinline__ double fast_exp(double x) { return exp(x); }
-__device__ __forceinline__ float fast_div(float a, float b) { return __fdividef(a, b); }
-__device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
+// exp(-r2 / 2) as ONE v_exp_f32 (2^x) after a single multiply; ~1 ulp, far inside the 1e-4 budget
+__device__ __forceinline__ float gauss_exp(float r2) { return __builtin_amdgcn_exp2f(r2 * -0.72134752044448170368f); }
+__device__ __forceinline__ double gauss_exp(double r2) { return exp(-0.5 * r2); }
+// 1 / x as ONE v_rcp_f32 (1 ulp)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 
 template <typename T, int F, int BATCH>
 __device__ __forceinline__ void stage_batch(const T* __restrict__ points, const T* __restrict__ feats,
@@ -54,6 +59,8 @@ __device__ __forceinline__ void stage_batch(const T* __restrict__ points, const 
     s.mx = g[0]; s.my = g[1]; s.ax = g[2]; s.ay = g[3];
     s.sx = g[4]; s.sy = g[5]; s.alpha = g[6];
     s.isx = T(1) / s.sx; s.isy = T(1) / s.sy;
+    s.A = s.ax * s.isx; s.B = s.ay * s.isx;
+    s.C = -s.ay * s.isy; s.D = s.ax * s.isy;
 #pragma unroll
     for (int c = 0; c < F; ++c) s.f[c] = feats[(int64_t)id * F + c];
     s_splat[t] = s;
@@ -90,10 +97,63 @@ __device__ __forceinline__ T splat_pdf(const Splat<T, F>& s, T px, T py) {
     return gaussian_pdf_antialias(px, py, g);
   } else {
     const T dx = px - s.mx, dy = py - s.my;
-    const T tx = (dx * s.ax + dy * s.ay) * s.isx;
-    const T ty = (dy * s.ax - dx * s.ay) * s.isy;
-    return fast_exp(T(-0.5) * (tx * tx + ty * ty));
+    const T X = dx * s.A + dy * s.B;
+    const T Y = dx * s.C + dy * s.D;
+    return gauss_exp(X * X + Y * Y);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave64 reduction of NV per-lane values, committed with atomics.
+//
+// float: a halving butterfly.  At each of the two quad stages every lane keeps half of its values
+// and hands the other half to its partner (one v_cndmask pair + one v_add_dpp quad_perm per value
+// pair), so NV values shrink to NV/4 registers whose lane (l & 3) selects the value; row_shr:4/8
+// finish the 16-lane rows, v_permlane16_swap / v_permlane32_swap (gfx950) halve again across rows
+// and wave halves.  ~40 VALU ops for 12 values instead of 72 for twelve 6-step DPP trees, and the
+// NV totals end up in NV DISTINCT lanes, so ONE global_atomic_add_f32 instruction commits them all
+// (the reference: 32-lane shuffle tree + shared atomics + global atomics, backward.py:200-224).
+// double (test-only path): plain ds_bpermute butterflies + one atomic per value from lane 63.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float keep, float send) {
+  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+
+// index of the value whose total lane `lane` holds after wave_reduce16 (valid when (lane & 15) >= 12)
+__device__ __forceinline__ int butterfly_slot(int lane) {
+  return 4 * (2 * (lane >> 5) + ((lane >> 4) & 1)) + (lane & 3);
+}
+
+// v[0..15] -> total of value butterfly_slot(lane) in the lanes with (lane & 15) >= 12
+__device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float r1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+    const float send = b0 ? v[2 * i] : v[2 * i + 1];
+    r1[i] = add_dpp<0xB1>(keep, send);                      // quad_perm:[1,0,3,2]
+  }
+  float r2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = b1 ? r1[2 * j + 1] : r1[2 * j];
+    const float send = b1 ? r1[2 * j] : r1[2 * j + 1];
+    r2[j] = add_dpp<0x4E>(keep, send);                      // quad_perm:[2,3,0,1]
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r2[j] = add_dpp<0x114>(r2[j], r2[j]);                   // row_shr:4
+    r2[j] = add_dpp<0x118>(r2[j], r2[j]);                   // row_shr:8
+  }
+  // rows: (r2[0], r2[1]) and (r2[2], r2[3]) -> even rows keep the first, odd rows the second
+  const auto p0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[0]), __float_as_uint(r2[1]), false, false);
+  const auto p1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[2]), __float_as_uint(r2[3]), false, false);
+  const float s0 = __uint_as_float(p0[0]) + __uint_as_float(p0[1]);
+  const float s1 = __uint_as_float(p1[0]) + __uint_as_float(p1[1]);
+  const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+  return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,6 +245,58 @@ raster_fwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
   }
 }
 
+// destination word of the value a lane holds after wave_reduce16: value k < 7 -> grad_points[id][k],
+// k < 7+F -> grad_feats[id][k-7], then the two heuristics
+template <typename T, int F, bool HEUR>
+__device__ __forceinline__ void grad_target(int lane, T* grad_points, T* grad_feats, T* heuristic,
+                                            T*& base, int& stride) {
+  base = nullptr; stride = 0;
+  if ((lane & 15) < 12) return;
+  const int k = butterfly_slot(lane);
+  if (k < 7) { if (grad_points) { base = grad_points + k; stride = 7; } }
+  else if (k < 7 + F) { if (grad_feats) { base = grad_feats + (k - 7); stride = F; } }
+  else if (HEUR && k < 7 + F + 2) { if (heuristic) { base = heuristic + (k - 7 - F); stride = 2; } }
+}
+
+template <typename T, int F, bool HEUR>
+__device__ __forceinline__ void commit_gradients(const T (&v)[16], int32_t id, int lane, T* tgt_base,
+                                                 int tgt_stride, T* grad_points, T* grad_feats, T* heuristic);
+
+template <>
+__device__ __forceinline__ void commit_gradients<float, 1, false>(const float (&v)[16], int32_t id, int lane, float* b, int st, float*, float*, float*) {
+  const float total = wave_reduce16(v, lane);
+  if (b) atomic_add_noret(b + (int64_t)id * st, total);
+}
+#define MS_COMMIT_F32(F, HEUR)                                                                                   \
+  template <>                                                                                                    \
+  __device__ __forceinline__ void commit_gradients<float, F, HEUR>(const float (&v)[16], int32_t id, int lane,   \
+                                                                   float* b, int st, float*, float*, float*) {   \
+    const float total = wave_reduce16(v, lane);                                                                  \
+    if (b) atomic_add_noret(b + (int64_t)id * st, total);                                                        \
+  }
+MS_COMMIT_F32(1, true) MS_COMMIT_F32(2, false) MS_COMMIT_F32(2, true) MS_COMMIT_F32(3, false)
+MS_COMMIT_F32(3, true) MS_COMMIT_F32(4, false) MS_COMMIT_F32(4, true)
+#undef MS_COMMIT_F32
+
+// double: test-only path, one tree reduction + one atomic per value
+#define MS_COMMIT_F64(F, HEUR)                                                                                   \
+  template <>                                                                                                    \
+  __device__ __forceinline__ void commit_gradients<double, F, HEUR>(const double (&v)[16], int32_t id, int lane, \
+                                                                    double*, int, double* gp, double* gf,        \
+                                                                    double* heur) {                              \
+    for (int k = 0; k < 7 + F + (HEUR ? 2 : 0); ++k) {                                                           \
+      const double total = wave_sum_to_lane63(v[k]);                                                             \
+      if (lane == 63) {                                                                                          \
+        if (k < 7) { if (gp) atomic_add_noret(gp + (int64_t)id * 7 + k, total); }                                \
+        else if (k < 7 + F) { if (gf) atomic_add_noret(gf + (int64_t)id * F + (k - 7), total); }                 \
+        else if (heur) atomic_add_noret(heur + (int64_t)id * 2 + (k - 7 - F), total);                            \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+MS_COMMIT_F64(1, false) MS_COMMIT_F64(1, true) MS_COMMIT_F64(2, false) MS_COMMIT_F64(2, true)
+MS_COMMIT_F64(3, false) MS_COMMIT_F64(3, true) MS_COMMIT_F64(4, false) MS_COMMIT_F64(4, true)
+#undef MS_COMMIT_F64
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -225,6 +337,11 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
 
   const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
 
+  // float path: which output word this lane commits after the butterfly (see wave_reduce16)
+  T* tgt_base = nullptr;
+  int tgt_stride = 0;
+  grad_target<T, F, HEUR>(lane, grad_points, grad_feats, heuristic, tgt_base, tgt_stride);
+
   for (int begin = start; begin < end; begin += BATCH) {
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     // tile-wide early out once every pixel is saturated (backward.py:116)
@@ -245,80 +362,63 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
         m &= m - 1;
         const Splat<T, F>& s = s_splat[r + b];
 
-        T dmean[2], daxis[2], dsigma[2];
+        // per-pixel partial gradients of the packed 2D gaussian, before the aag factor:
+        //   gm = dp/dmean, ga = dp/daxis, gs = dp/dsigma   (generic.py:321-336 / :371-404)
+        T gm[2], ga[2], gs[2];
         T p;
         if (AA) {
           const T g[6] = {s.mx, s.my, s.ax, s.ay, s.sx, s.sy};
-          p = gaussian_pdf_antialias_with_grad(px, py, g, dmean, daxis, dsigma);
+          p = gaussian_pdf_antialias_with_grad(px, py, g, gm, ga, gs);
         } else {
           const T dx = px - s.mx, dy = py - s.my;
-          const T tx = (dx * s.ax + dy * s.ay) * s.isx;
-          const T ty = (dy * s.ax - dx * s.ay) * s.isy;
-          const T tx2 = tx * tx, ty2 = ty * ty;
-          p = fast_exp(T(-0.5) * (tx2 + ty2));
-          dsigma[0] = tx2 * p * s.isx;
-          dsigma[1] = ty2 * p * s.isy;
-          const T tx_s = tx * s.isx * p, ty_s = ty * s.isy * p;
-          daxis[0] = -(tx_s * dx + ty_s * dy);
-          daxis[1] = ty_s * dx - tx_s * dy;
-          dmean[0] = tx_s * s.ax - ty_s * s.ay;
-          dmean[1] = tx_s * s.ay + ty_s * s.ax;
+          const T X = dx * s.A + dy * s.B;
+          const T Y = dx * s.C + dy * s.D;
+          p = gauss_exp(X * X + Y * Y);
+          const T pX = p * X, pY = p * Y;
+          gm[0] = pX * s.A + pY * s.C;           // p (X/sx * axis + Y/sy * perp(axis))
+          gm[1] = pX * s.B + pY * s.D;
+          const T u = pX * s.isx, w = pY * s.isy;
+          ga[0] = -(u * dx + w * dy);            // p (X/sx * -d + Y/sy * perp(d))
+          ga[1] = w * dx - u * dy;
+          gs[0] = u * X;                         // p (X^2 / sx, Y^2 / sy)
+          gs[1] = w * Y;
         }
 
-        T acc[7 + F + 2];
+        const T alpha_raw = s.alpha * p;
+        const bool active = alpha_raw > rp.alpha_threshold && W < rp.saturate_threshold;
+        const T alpha = t_min(alpha_raw, rp.clamp_max_alpha);
+        const T Ti = T(1) - W;
+        const T weight = active ? alpha * Ti : T(0);
+        W += weight;
+        const T inv = fast_rcp(T(1) - alpha);
+        T alpha_grad = T(0);
 #pragma unroll
-        for (int k = 0; k < 7 + F + 2; ++k) acc[k] = T(0);
-
-        T alpha = s.alpha * p;
-        const bool active = alpha > rp.alpha_threshold && W < rp.saturate_threshold;
-        if (active) {
-          alpha = t_min(alpha, rp.clamp_max_alpha);
-          const T Ti = T(1) - W;
-          const T weight = alpha * Ti;
-          W += weight;
-          const T inv = fast_div(T(1), T(1) - alpha);
-          T alpha_grad = T(0);
-#pragma unroll
-          for (int c = 0; c < F; ++c) {
-            R[c] -= s.f[c] * weight;
-            alpha_grad += (s.f[c] * Ti - R[c] * inv) * G[c];
-            acc[7 + c] = weight * G[c];
-          }
-          const T aag = s.alpha * alpha_grad;   // straight-through clamp (backward.py:158-163)
-          acc[0] = aag * dmean[0]; acc[1] = aag * dmean[1];
-          acc[2] = aag * daxis[0]; acc[3] = aag * daxis[1];
-          acc[4] = aag * dsigma[0]; acc[5] = aag * dsigma[1];
-          acc[6] = p * alpha_grad;
-          if (HEUR) {
-            acc[7 + F] = aag * aag;
-            acc[7 + F + 1] = t_abs(acc[0]) + t_abs(acc[1]);
-          }
+        for (int c = 0; c < F; ++c) {
+          R[c] -= s.f[c] * weight;
+          alpha_grad += (s.f[c] * Ti - R[c] * inv) * G[c];
         }
+        alpha_grad = active ? alpha_grad : T(0);
+        const T aag = s.alpha * alpha_grad;      // straight-through clamp (backward.py:158-163)
 
-        if (__ballot(active)) {
-          const int32_t id = s_id[r + b];
-          if (grad_points) {
+        if (__ballot(active) == 0) continue;     // no pixel of this patch contributes
+
+        constexpr int NV = 7 + F + (HEUR ? 2 : 0);
+        T v[16];
+        v[0] = aag * gm[0]; v[1] = aag * gm[1];
+        v[2] = aag * ga[0]; v[3] = aag * ga[1];
+        v[4] = aag * gs[0]; v[5] = aag * gs[1];
+        v[6] = p * alpha_grad;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-              const T total = wave_sum_to_lane63(acc[k]);
-              if (lane == 63) atomic_add_noret(grad_points + (int64_t)id * 7 + k, total);
-            }
-          }
-          if (grad_feats) {
-#pragma unroll
-            for (int c = 0; c < F; ++c) {
-              const T total = wave_sum_to_lane63(acc[7 + c]);
-              if (lane == 63) atomic_add_noret(grad_feats + (int64_t)id * F + c, total);
-            }
-          }
-          if (HEUR) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const T total = wave_sum_to_lane63(acc[7 + F + k]);
-              if (lane == 63) atomic_add_noret(heuristic + (int64_t)id * 2 + k, total);
-            }
-          }
+        for (int c = 0; c < F; ++c) v[7 + c] = weight * G[c];
+        if (HEUR) {
+          v[7 + F] = aag * aag;
+          v[7 + F + 1] = t_abs(v[0]) + t_abs(v[1]);
         }
+#pragma unroll
+        for (int k = NV; k < 16; ++k) v[k] = T(0);
+
+        const int32_t id = s_id[r + b];
+        commit_gradients<T, F, HEUR>(v, id, lane, tgt_base, tgt_stride, grad_points, grad_feats, heuristic);
       }
     }
   }

@@ -98,6 +98,59 @@ sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
   }
 }
 
+
+// Fast parameter-gradient path: d params[idx, c, d] = g_out[i, c] * [0 < out[i, c] < 1] * Y_d(dir).
+// Phase 1 (lane = gaussian) evaluates the basis and the masked colour gradient into LDS; phase 2
+// (lanes = the F*D coefficients of ONE gaussian row) streams the rows out with full-line stores,
+// so the 4*F*D bytes per gaussian (192 B for RGB degree 3) leave the CU coalesced instead of as
+// 48 scattered 4-byte atomics per thread.  UNIQUE (indexes come from the projection compaction, no
+// repeats) uses plain stores; otherwise the same rows are accumulated with atomics.
+template <typename T, int DEG, bool UNIQUE>
+__global__ void __launch_bounds__(256)
+sh_bwd_params_kernel(const T* __restrict__ positions, const int64_t* __restrict__ indexes,
+                     const T* __restrict__ cam_pos, int64_t v, int f, const T* __restrict__ out,
+                     const T* __restrict__ g_out, T* __restrict__ g_params) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  constexpr int YS = D + 1;                 // padded row stride: conflict-free phase-1 writes
+  __shared__ T s_Y[4][64 * YS];
+  __shared__ T s_g[4][64 * SH_MAX_F];
+  __shared__ int64_t s_idx[4][64];
+
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
+  if (base >= v) return;
+  const int64_t i = base + lane;
+  const int count = (v - base) < 64 ? (int)(v - base) : 64;
+
+  if (lane < count) {
+    const int64_t idx = indexes[i];
+    const T dx = positions[idx * 3 + 0] - cam_pos[0];
+    const T dy = positions[idx * 3 + 1] - cam_pos[1];
+    const T dz = positions[idx * 3 + 2] - cam_pos[2];
+    const T len = t_sqrt(dx * dx + dy * dy + dz * dz);
+    T Y[D];
+    sh_basis<T, DEG>(dx / len, dy / len, dz / len, Y);
+#pragma unroll
+    for (int d = 0; d < D; ++d) s_Y[wave][lane * YS + d] = Y[d];
+    for (int c = 0; c < f; ++c) {
+      const T o = out[i * f + c];
+      s_g[wave][lane * SH_MAX_F + c] = (o > T(0) && o < T(1)) ? g_out[i * f + c] : T(0);
+    }
+    s_idx[wave][lane] = idx;
+  }
+  __builtin_amdgcn_wave_barrier();   // LDS traffic stays inside the wave: no block barrier needed
+
+  const int row = f * D;
+  for (int j = 0; j < count; ++j) {
+    T* dst = g_params + s_idx[wave][j] * row;
+    for (int e = lane; e < row; e += 64) {
+      const T val = s_g[wave][j * SH_MAX_F + e / D] * s_Y[wave][j * YS + e % D];
+      if (UNIQUE) dst[e] = val;
+      else atomic_add_noret(dst + e, val);
+    }
+  }
+}
+
 template <typename T>
 static int launch_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
                          const void* cam, int64_t v, int f, int degree, void* out, hipStream_t s) {
@@ -116,9 +169,26 @@ static int launch_sh_fwd(const void* params, const void* positions, const int64_
 
 template <typename T>
 static int launch_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
-                         const void* cam, int64_t v, int f, int degree, const void* g_out,
-                         void* g_params, void* g_positions, void* g_cam, hipStream_t s) {
+                         const void* cam, int64_t v, int f, int degree, const void* out, const void* g_out,
+                         void* g_params, void* g_positions, void* g_cam, int unique, hipStream_t s) {
   const dim3 block(256), grid((unsigned)div_up(v, 256));
+  if (out && g_params && !g_positions && !g_cam && f <= SH_MAX_F) {
+#define MS_SH_BWD_P(DEG)                                                                                  \
+  do {                                                                                                    \
+    if (unique) sh_bwd_params_kernel<T, DEG, true><<<grid, block, 0, s>>>((const T*)positions, indexes,   \
+        (const T*)cam, v, f, (const T*)out, (const T*)g_out, (T*)g_params);                               \
+    else sh_bwd_params_kernel<T, DEG, false><<<grid, block, 0, s>>>((const T*)positions, indexes,         \
+        (const T*)cam, v, f, (const T*)out, (const T*)g_out, (T*)g_params);                               \
+  } while (0)
+    switch (degree) {
+      case 0: MS_SH_BWD_P(0); break;
+      case 1: MS_SH_BWD_P(1); break;
+      case 2: MS_SH_BWD_P(2); break;
+      default: MS_SH_BWD_P(3); break;
+    }
+#undef MS_SH_BWD_P
+    return 0;
+  }
 #define MS_SH_BWD(DEG)                                                                              \
   sh_bwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, indexes,      \
                                                 (const T*)cam, v, f, (const T*)g_out, (T*)g_params, \
@@ -153,17 +223,17 @@ extern "C" int ms_sh_fwd(const void* params, const void* positions, const int64_
 }
 
 extern "C" int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
-                         const void* camera_pos, int64_t v, int f, int degree, const void* grad_out,
-                         void* grad_params, void* grad_positions, void* grad_camera_pos, int dtype,
-                         void* stream) {
+                         const void* camera_pos, int64_t v, int f, int degree, const void* out,
+                         const void* grad_out, void* grad_params, void* grad_positions,
+                         void* grad_camera_pos, int unique_indexes, int dtype, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
   MS_CHECK_ARG(degree >= 0 && degree <= 3, "degree must be in [0, 3]");
   MS_CHECK_ARG(f >= 1, "f < 1");
   MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
   if (v == 0) return 0;
   MS_CHECK_ARG(params && positions && indexes && camera_pos && grad_out, "null pointer");
-  if (dtype == MS_F32) launch_sh_bwd<float>(params, positions, indexes, camera_pos, v, f, degree, grad_out, grad_params, grad_positions, grad_camera_pos, (hipStream_t)stream);
-  else launch_sh_bwd<double>(params, positions, indexes, camera_pos, v, f, degree, grad_out, grad_params, grad_positions, grad_camera_pos, (hipStream_t)stream);
+  if (dtype == MS_F32) launch_sh_bwd<float>(params, positions, indexes, camera_pos, v, f, degree, out, grad_out, grad_params, grad_positions, grad_camera_pos, unique_indexes, (hipStream_t)stream);
+  else launch_sh_bwd<double>(params, positions, indexes, camera_pos, v, f, degree, out, grad_out, grad_params, grad_positions, grad_camera_pos, unique_indexes, (hipStream_t)stream);
   MS_CHECK_LAUNCH();
   return 0;
 }

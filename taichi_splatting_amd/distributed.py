@@ -74,7 +74,7 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
   # per-gaussian stages: replicated
   gaussians2d, depths, indexes = project_to_image(gaussians, camera_params, config)
   if use_sh:
-    features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_params.camera_position)
+    features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_params.camera_position, unique_indexes=True)
   else:
     features = gaussians.feature[indexes]
 

@@ -45,7 +45,7 @@ def render_gaussians(
 
   if use_sh:
     features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes,
-                              camera_params.camera_position)
+                              camera_params.camera_position, unique_indexes=True)
   else:
     features = gaussians.feature[indexes]
     assert len(features.shape) == 2, f"Features must be (N, C) if use_sh=False, got {features.shape}"
