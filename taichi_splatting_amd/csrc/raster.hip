@@ -495,6 +495,14 @@ static int dispatch_ts_bwd(int ts, Args... args) {
 
 using namespace ms;
 
+// product-path kernels (float, F = 3, plain pdf, blending): raster_fast.hip
+bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
+                        int num_tiles, hipStream_t s);
+bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                        const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
+                        void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
+
 static int check_raster_common(const ms_raster_config* cfg, int w, int h, int f, int dtype, int* row_begin,
                                int* row_end, const char* fn) {
   if (!cfg) { set_error("%s: cfg is null", fn); return MS_ERR_BAD_ARG; }
@@ -525,6 +533,14 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
   const int tiles_wide = (image_w + cfg->tile_size - 1) / cfg->tile_size;
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending &&
+      !(cfg->compute_visibility && out_visibility)) {
+    if (ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
+                           out_alpha, tile_row_begin, num_tiles, s)) {
+      MS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
 #define MS_GO(T, F) rc = dispatch_ts_fwd<T, F>(cfg->tile_size, points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image, out_alpha, out_visibility, tile_row_begin, num_tiles, s)
   if (dtype == MS_F32) {
     switch (f) { case 1: MS_GO(float, 1); break; case 2: MS_GO(float, 2); break; case 3: MS_GO(float, 3); break; default: MS_GO(float, 4); break; }
@@ -551,6 +567,13 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
   const int tiles_wide = (image_w + cfg->tile_size - 1) / cfg->tile_size;
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == MS_F32 && f == 3 && !cfg->antialias) {
+    if (ms_raster_bwd_fast(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
+                           cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)) {
+      MS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
 #define MS_GO(T, F) rc = dispatch_ts_bwd<T, F>(cfg->tile_size, points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)
   if (dtype == MS_F32) {
     switch (f) { case 1: MS_GO(float, 1); break; case 2: MS_GO(float, 2); break; case 3: MS_GO(float, 3); break; default: MS_GO(float, 4); break; }

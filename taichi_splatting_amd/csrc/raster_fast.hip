@@ -1,0 +1,400 @@
+// raster_fast.hip — the product-path raster kernels: float32, RGB (F = 3), plain gaussian pdf,
+// alpha blending.  Same algorithm and work decomposition as the generic templates in raster.hip
+// (one workgroup per tile, one wave64 per 8x8 pixel patch, one lane per pixel; semantics of
+// rasterizer/forward.py:39-135 and rasterizer/backward.py:97-224), hand-tuned for gfx950:
+//
+//   * 48-byte LDS splat record read as three ds_read_b128 broadcasts, software-prefetched one hit
+//     ahead so LDS latency overlaps the arithmetic of the current splat;
+//   * exact-ish culling per wave: axis-aligned extent test AND the oriented-box separating-axis
+//     test of the tile mapper (grid_query.py:30-43) against the patch's pixel-centre rectangle,
+//     one staged splat per lane, ballot -> scalar walk over the hits;
+//   * no exec-mask divergence in the hot loop: contributions are predicated (v_cndmask);
+//   * transmittance T = 1 - W is carried instead of W (w = alpha * T; T -= w);
+//   * backward: halving-butterfly wave reduction (quad_perm DPP + v_permlane16/32_swap) and ONE
+//     global_atomic_add_f32 per (patch, splat) — see wave_reduce16;
+//   * the next batch's gather (overlap_to_point -> packed gaussian + colour) is issued before the
+//     current batch is consumed, hiding the dependent HBM/L2 gather latency behind the blend loop.
+#include "common.h"
+
+namespace ms {
+
+struct FastParams {
+  int width, height, tiles_wide, tile_begin;
+  float clamp_max_alpha, alpha_threshold, one_minus_saturate;
+};
+
+// raw per-splat data in flight between the gather and the LDS write (one batch ahead)
+struct Raw {
+  float g[7];
+  float f[3];
+  int id;
+};
+
+__device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const float* __restrict__ feats, int id) {
+  Raw r;
+  const float* g = points + (int64_t)id * 7;
+  const float* f = feats + (int64_t)id * 3;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) r.g[k] = g[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.f[k] = f[k];
+  r.id = id;
+  return r;
+}
+
+// LDS records of one splat: blend record [mx my A B] [C D alpha f0] [f1 f2 isx isy] and cull record
+// [cx cy ex ey] [A' B' C' D'] (inverse basis divided by the cutoff radius)
+__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull) {
+  const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
+  const float isx = 1.0f / sx, isy = 1.0f / sy;
+  const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
+  rec[0] = make_float4(mx, my, A, B);
+  rec[1] = make_float4(C, D, alpha, r.f[0]);
+  rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
+  // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
+  // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
+  const float gs = sqrtf(2.0f * logf(alpha / alpha_threshold)) * 1.001f;
+  const float v1x = ax * sx * gs, v1y = ay * sx * gs, v2x = -ay * sy * gs, v2y = ax * sy * gs;
+  cull[0] = make_float4(mx, my, sqrtf(v1x * v1x + v2x * v2x) + 0.01f, sqrtf(v1y * v1y + v2y * v2y) + 0.01f);
+  const float igs = 1.0f / gs;
+  cull[1] = make_float4(A * igs, B * igs, C * igs, D * igs);
+}
+
+// does the splat's contribution region possibly touch the pixel-centre rectangle of the patch
+// [x0 + .5, x0 + 7.5] x [y0 + .5, y0 + 7.5]?  Conservative: false only if provably no pixel passes.
+__device__ __forceinline__ bool patch_hit(const float4 c0, const float4 c1, float rcx, float rcy) {
+  const float dx = rcx - c0.x, dy = rcy - c0.y;   // rectangle centre relative to the mean
+  const float h = 3.5f;
+  // rectangle axes: |d| <= extent + h
+  bool hit = (fabsf(dx) <= c0.z + h) && (fabsf(dy) <= c0.w + h);
+  // ellipse axes (unit circle in the normalised frame): |c| - e <= 1 (+ margin)
+  const float p1 = c1.x * dx + c1.y * dy, e1 = (fabsf(c1.x) + fabsf(c1.y)) * h;
+  const float p2 = c1.z * dx + c1.w * dy, e2 = (fabsf(c1.z) + fabsf(c1.w)) * h;
+  hit = hit && (fabsf(p1) - e1 <= 1.002f) && (fabsf(p2) - e2 <= 1.002f);
+  return hit;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float keep, float send) {
+  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+
+// index of the value whose total lane `lane` holds after wave_reduce16 (valid when (lane & 15) >= 12)
+__device__ __forceinline__ int butterfly_slot(int lane) {
+  return 4 * (2 * (lane >> 5) + ((lane >> 4) & 1)) + (lane & 3);
+}
+
+// Halving butterfly: v[0..15] -> total of value butterfly_slot(lane) in lanes with (lane & 15) >= 12.
+// Quad stages: each lane keeps half of its values and hands the rest to its partner (2 v_cndmask +
+// 1 v_add_dpp quad_perm per value pair); row_shr:4/8 finish the 16-lane rows; v_permlane16_swap /
+// v_permlane32_swap (gfx950) halve again across rows and wave halves.
+__device__ __forceinline__ float wave_reduce16(const float (&v)[16], bool b0, bool b1) {
+  float r1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+    const float send = b0 ? v[2 * i] : v[2 * i + 1];
+    r1[i] = add_dpp<0xB1>(keep, send);                      // quad_perm:[1,0,3,2]
+  }
+  float r2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = b1 ? r1[2 * j + 1] : r1[2 * j];
+    const float send = b1 ? r1[2 * j] : r1[2 * j + 1];
+    r2[j] = add_dpp<0x4E>(keep, send);                      // quad_perm:[2,3,0,1]
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r2[j] = add_dpp<0x114>(r2[j], r2[j]);                   // row_shr:4
+    r2[j] = add_dpp<0x118>(r2[j], r2[j]);                   // row_shr:8
+  }
+  const auto p0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[0]), __float_as_uint(r2[1]), false, false);
+  const auto p1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[2]), __float_as_uint(r2[3]), false, false);
+  const float s0 = __uint_as_float(p0[0]) + __uint_as_float(p0[1]);
+  const float s1 = __uint_as_float(p1[0]) + __uint_as_float(p1[1]);
+  const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+  return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
+}
+
+constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
+
+template <int TS> struct TileGeom {
+  static constexpr int THREADS = TS * TS;
+  static constexpr int BATCH = THREADS < 256 ? THREADS : 256;
+  static constexpr int WAVES_WIDE = TS / 8;
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int TS>
+__global__ void __launch_bounds__(TS * TS)
+raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
+                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
+                        FastParams rp, float* __restrict__ image, float* __restrict__ image_alpha) {
+  using G = TileGeom<TS>;
+  constexpr int BATCH = G::BATCH;
+  __shared__ float4 s_rec[BATCH * 3];
+  __shared__ float4 s_cull[BATCH * 2];
+
+  const int tile_id = rp.tile_begin + blockIdx.x;
+  const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int patch_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8;
+  const int patch_y = tile_v * TS + (wave / G::WAVES_WIDE) * 8;
+  const int pix_x = patch_x + (lane & 7), pix_y = patch_y + (lane >> 3);
+  const float px = (float)pix_x + 0.5f, py = (float)pix_y + 0.5f;
+  const float rcx = (float)patch_x + 4.0f, rcy = (float)patch_y + 4.0f;
+  const bool in_bounds = pix_x < rp.width && pix_y < rp.height;
+
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+  float T = in_bounds ? 1.0f : 0.0f;     // transmittance = 1 - accumulated weight
+
+  const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
+  const int t = threadIdx.x;
+
+  // two-deep gather pipeline: `raw` = splat data of the batch about to be staged, `next_id` = point
+  // index of the batch after it, so neither dependent load is waited for inside the blend loop
+  Raw raw;
+  int next_id = 0;
+  const bool stager = t < BATCH;
+  if (stager && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
+  if (stager && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
+
+  for (int begin = start; begin < end; begin += BATCH) {
+    const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
+    __syncthreads();                       // previous batch fully consumed
+    if (stager && begin + t < end) write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
+    if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
+    if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
+    __syncthreads();
+
+    for (int r = 0; r < count; r += 64) {
+      const int j = r + lane;
+      bool hit = false;
+      if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
+      unsigned long long m = __ballot(hit);
+      if (m == 0) continue;
+      int b = __builtin_ctzll(m);
+      m &= m - 1;
+      float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1], q2 = s_rec[(r + b) * 3 + 2];
+      while (true) {
+        const bool more = m != 0;
+        const int nb = more ? __builtin_ctzll(m) : b;
+        m &= m - 1;
+        // prefetch the next hit's record (re-reads the current one on the last iteration)
+        const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1], n2 = s_rec[(r + nb) * 3 + 2];
+
+        const float dx = px - q0.x, dy = py - q0.y;
+        const float X = dx * q0.z + dy * q0.w;
+        const float Y = dx * q1.x + dy * q1.y;
+        const float g = __builtin_amdgcn_exp2f((X * X + Y * Y) * EXP2_SCALE);
+        const float a = fminf(q1.z * g, rp.clamp_max_alpha);
+        const float w = a > rp.alpha_threshold ? a * T : 0.0f;
+        T -= w;
+        c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
+
+        if (!more) break;
+        b = nb; q0 = n0; q1 = n1; q2 = n2;
+      }
+    }
+  }
+
+  if (in_bounds) {
+    const int64_t p = (int64_t)pix_y * rp.width + pix_x;
+    image[p * 3 + 0] = c0; image[p * 3 + 1] = c1; image[p * 3 + 2] = c2;
+    image_alpha[p] = 1.0f - T;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+template <int TS, bool HEUR>
+__global__ void __launch_bounds__(TS * TS)
+raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
+                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
+                        const float* __restrict__ image, const float* __restrict__ grad_image,
+                        FastParams rp, float* __restrict__ grad_points, float* __restrict__ grad_feats,
+                        float* __restrict__ heuristic) {
+  using G = TileGeom<TS>;
+  constexpr int BATCH = G::BATCH;
+  __shared__ float4 s_rec[BATCH * 3];
+  __shared__ float4 s_cull[BATCH * 2];
+  __shared__ int32_t s_id[BATCH];
+
+  const int tile_id = rp.tile_begin + blockIdx.x;
+  const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int patch_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8;
+  const int patch_y = tile_v * TS + (wave / G::WAVES_WIDE) * 8;
+  const int pix_x = patch_x + (lane & 7), pix_y = patch_y + (lane >> 3);
+  const float px = (float)pix_x + 0.5f, py = (float)pix_y + 0.5f;
+  const float rcx = (float)patch_x + 4.0f, rcy = (float)patch_y + 4.0f;
+  const bool in_bounds = pix_x < rp.width && pix_y < rp.height;
+
+  // per-pixel state (backward.py:97-110): T = 1 - W, R colour still to come, G = dL/dC
+  float R0 = 0.f, R1 = 0.f, R2 = 0.f, G0 = 0.f, G1 = 0.f, G2 = 0.f;
+  float T = 0.0f;
+  if (in_bounds) {
+    const int64_t p = (int64_t)pix_y * rp.width + pix_x;
+    R0 = image[p * 3 + 0]; R1 = image[p * 3 + 1]; R2 = image[p * 3 + 2];
+    G0 = grad_image[p * 3 + 0]; G1 = grad_image[p * 3 + 1]; G2 = grad_image[p * 3 + 2];
+    T = 1.0f;
+  }
+
+  // which output word this lane commits after the butterfly: value k < 7 -> grad_points[id][k],
+  // k < 10 -> grad_feats[id][k - 7], then the two heuristics
+  float* tgt = nullptr;
+  unsigned tgt_stride = 0;
+  if ((lane & 15) >= 12) {
+    const int k = butterfly_slot(lane);
+    if (k < 7) { if (grad_points) { tgt = grad_points + k; tgt_stride = 7; } }
+    else if (k < 10) { if (grad_feats) { tgt = grad_feats + (k - 7); tgt_stride = 3; } }
+    else if (HEUR && k < 12) { if (heuristic) { tgt = heuristic + (k - 10); tgt_stride = 2; } }
+  }
+  const bool b0 = lane & 1, b1 = lane & 2;
+
+  const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
+  const int t = threadIdx.x;
+
+  Raw raw;
+  int next_id = 0;
+  const bool stager = t < BATCH;
+  if (stager && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
+  if (stager && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
+
+  for (int begin = start; begin < end; begin += BATCH) {
+    const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
+    // tile-wide early out once every pixel is saturated (backward.py:116)
+    if (__syncthreads_and(T <= rp.one_minus_saturate)) break;
+    if (stager && begin + t < end) {
+      write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
+      s_id[t] = raw.id;
+    }
+    if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
+    if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
+    __syncthreads();
+
+    // wave-wide early out (backward.py:142)
+    if (__ballot(T > rp.one_minus_saturate) == 0) continue;
+
+    for (int r = 0; r < count; r += 64) {
+      const int j = r + lane;
+      bool hit = false;
+      if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
+      unsigned long long m = __ballot(hit);
+      if (m == 0) continue;
+      int b = __builtin_ctzll(m);
+      m &= m - 1;
+      float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1], q2 = s_rec[(r + b) * 3 + 2];
+      while (true) {
+        const bool more = m != 0;
+        const int nb = more ? __builtin_ctzll(m) : b;
+        m &= m - 1;
+        const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1], n2 = s_rec[(r + nb) * 3 + 2];
+
+        const float A = q0.z, B = q0.w, C = q1.x, D = q1.y, alpha_pt = q1.z;
+        const float f0 = q1.w, f1 = q2.x, f2 = q2.y, isx = q2.z, isy = q2.w;
+        const float dx = px - q0.x, dy = py - q0.y;
+        const float X = dx * A + dy * B;
+        const float Y = dx * C + dy * D;
+        const float g = __builtin_amdgcn_exp2f((X * X + Y * Y) * EXP2_SCALE);
+        const float a_raw = alpha_pt * g;
+        const bool active = (a_raw > rp.alpha_threshold) && (T > rp.one_minus_saturate);
+
+        if (__ballot(active) != 0) {
+          const float a = fminf(a_raw, rp.clamp_max_alpha);
+          const float w = active ? a * T : 0.0f;
+          const float inv = __builtin_amdgcn_rcpf(1.0f - a);
+          R0 -= f0 * w; R1 -= f1 * w; R2 -= f2 * w;
+          // d(alpha): sum_c (f_c T - R_c / (1 - alpha)) G_c  (backward.py:171-175), T before the update
+          float ag = (f0 * T - R0 * inv) * G0 + (f1 * T - R1 * inv) * G1 + (f2 * T - R2 * inv) * G2;
+          ag = active ? ag : 0.0f;
+          T -= w;
+          const float aag = alpha_pt * ag;            // straight-through clamp (backward.py:158-163)
+
+          // dp/dmean = g (X/sx axis + Y/sy perp(axis)); dp/daxis = g (X/sx (-d) + Y/sy perp(d));
+          // dp/dsigma = g (X^2/sx, Y^2/sy)   (generic.py:321-336), all scaled by aag
+          const float qX = aag * g * X, qY = aag * g * Y;
+          const float u = qX * isx, wv = qY * isy;
+          float v[16];
+          v[0] = qX * A + qY * C;
+          v[1] = qX * B + qY * D;
+          v[2] = -(u * dx + wv * dy);
+          v[3] = wv * dx - u * dy;
+          v[4] = u * X;
+          v[5] = wv * Y;
+          v[6] = g * ag;
+          v[7] = w * G0; v[8] = w * G1; v[9] = w * G2;
+          if (HEUR) {
+            v[10] = aag * aag;                         // backward.py:190-194
+            v[11] = fabsf(v[0]) + fabsf(v[1]);
+          } else {
+            v[10] = 0.f; v[11] = 0.f;
+          }
+          v[12] = 0.f; v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
+
+          const float total = wave_reduce16(v, b0, b1);
+          if (tgt) {
+            const unsigned id = (unsigned)s_id[r + b];
+            atomic_add_noret(tgt + (size_t)(id * tgt_stride), total);
+          }
+        }
+
+        if (!more) break;
+        b = nb; q0 = n0; q1 = n1; q2 = n2;
+      }
+    }
+  }
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, int row_begin) {
+  FastParams rp;
+  rp.width = w; rp.height = h;
+  rp.tiles_wide = (w + cfg->tile_size - 1) / cfg->tile_size;
+  rp.tile_begin = row_begin * rp.tiles_wide;
+  rp.clamp_max_alpha = (float)cfg->clamp_max_alpha;
+  rp.alpha_threshold = (float)cfg->alpha_threshold;
+  rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
+  return rp;
+}
+
+// Called from raster.hip's dispatch.  Returns true if the fast path handled the launch.
+bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
+                        int num_tiles, hipStream_t s) {
+  const FastParams rp = make_fast_params(w, h, cfg, row_begin);
+  const dim3 grid((unsigned)num_tiles);
+#define MS_GO(TS) raster_fwd_f32x3_kernel<TS><<<grid, dim3(TS * TS), 0, s>>>(                               \
+      (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha)
+  switch (cfg->tile_size) {
+    case 8: MS_GO(8); return true;
+    case 16: MS_GO(16); return true;
+    case 32: MS_GO(32); return true;
+  }
+#undef MS_GO
+  return false;
+}
+
+bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                        const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
+                        void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s) {
+  const FastParams rp = make_fast_params(w, h, cfg, row_begin);
+  const dim3 grid((unsigned)num_tiles);
+  const bool hf = cfg->compute_point_heuristic && heur;
+#define MS_GO(TS, HEUR) raster_bwd_f32x3_kernel<TS, HEUR><<<grid, dim3(TS * TS), 0, s>>>(                   \
+      (const float*)points, (const float*)feats, ranges, o2p, (const float*)image, (const float*)grad_image, \
+      rp, (float*)gp, (float*)gf, (float*)heur)
+  switch (cfg->tile_size) {
+    case 8: if (hf) MS_GO(8, true); else MS_GO(8, false); return true;
+    case 16: if (hf) MS_GO(16, true); else MS_GO(16, false); return true;
+    case 32: if (hf) MS_GO(32, true); else MS_GO(32, false); return true;
+  }
+#undef MS_GO
+  return false;
+}

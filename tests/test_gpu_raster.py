@@ -193,3 +193,39 @@ def test_empty_inputs_and_requires_grad_subsets():
   out = rasterize_with_tiles(p.to(DEV), fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
   out.image.sum().backward()
   assert fg.grad is not None and fg.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize('tile_size', [8, 16, 32])
+@pytest.mark.parametrize('n,size,scale,alpha', [(20000, (333, 200), 1.0, (0.1, 0.9)), (8000, (96, 64), 6.0, (0.6, 1.0)),
+                                                 (200000, (1024, 768), 1.0, (0.1, 0.9))])
+def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale, alpha):
+  # the hand-tuned float/RGB kernels (raster_fast.hip) against the generic f64 instantiation
+  # (itself checked against the oracle above), incl. many LDS batches per tile, image sizes that are
+  # not tile multiples, point heuristics
+  torch.manual_seed(n + tile_size)
+  cfg = cfg_for(tile_size, compute_point_heuristic=True)
+  g = random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha).to(DEV)
+  p32 = project_gaussians2d(g)
+  o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
+  ranges = ranges.view(-1, 2)
+  torch.manual_seed(1)
+  G = torch.randn(size[1], size[0], 3, device=DEV)
+  res = {}
+  for dtype in (torch.float64, torch.float32):
+    p = p32.to(dtype).clone().requires_grad_(True)
+    f = g.feature.to(dtype).clone().requires_grad_(True)
+    out = rasterize_with_tiles(p, f, o2p, ranges, size, cfg)
+    (out.image * G.to(dtype)).sum().backward()
+    res[dtype] = (out.image.detach().double(), out.image_weight.detach().double(), p.grad.double(), f.grad.double(),
+                  out.point_heuristic.double())
+  img64, a64, gp64, gf64, h64 = res[torch.float64]
+  img32, a32, gp32, gf32, h32 = res[torch.float32]
+  err = (img32 - img64).abs().max(-1).values
+  # a contribution gate (alpha > 1/255) flipping in f32 moves a pixel by ~alpha_threshold * |f|
+  assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2, (err.quantile(0.9999), err.max())
+  assert (a32 - a64).abs().quantile(0.9999) < 1e-4
+  for got, want in ((gp32, gp64), (gf32, gf64), (h32, h64)):
+    scale_ = want.abs().max().item() + 1e-12
+    rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
+    assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
+    assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
