@@ -89,10 +89,12 @@ class _ProjectFunction(torch.autograd.Function):
     indexes = ctx.indexes
     v = indexes.shape[0]
 
-    grad_position = torch.zeros_like(position)
-    grad_log_scaling = torch.zeros_like(log_scaling)
-    grad_rotation = torch.zeros_like(rotation)
-    grad_alpha_logit = torch.zeros_like(alpha_logit)
+    # the kernel WRITES the rows listed in indexes; only culled rows need the zero fill
+    alloc = torch.empty_like if v == position.shape[0] else torch.zeros_like
+    grad_position = alloc(position)
+    grad_log_scaling = alloc(log_scaling)
+    grad_rotation = alloc(rotation)
+    grad_alpha_logit = alloc(alpha_logit)
     need_camera = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
     grad_camera = torch.zeros((16,), dtype=dtype, device=device) if need_camera else None
 
