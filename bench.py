@@ -265,9 +265,18 @@ def main():
     alg = algorithmic_bytes(args.n, V, K, P, T, F, D, passes)
     dom = 'raster_bwd'
     achieved = alg[dom] / (stages[dom] * 1e-3) / 1e9
-    result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_kernel<float,3,%d>" % args.tile,
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE), valid
+    # only for the workload they were collected on
+    traffic = None
+    try:
+      t = json.load(open(ROOT / 'profiles' / 'r01_raster_hbm_traffic.json'))
+      if (t['workload']['n'], t['workload']['size'], t['workload']['tile']) == (args.n, w, args.tile) and w == h:
+        traffic = t['raster_bwd_f32x3_kernel<16,false>']['traffic_bytes']
+    except Exception:
+      traffic = None
+    result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_f32x3_kernel<%d>" % args.tile,
                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                           "kernel_ms": round(stages[dom], 4), "algorithmic_bytes": alg[dom],
                           "note": "alpha-composite passes are VALU/LDS bound at these K*tile^2 (SURVEY 8d)"}
     frame_bytes = sum(alg.values())
