@@ -109,13 +109,22 @@ int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
               void* grad_camera_pos, int unique_indexes, int dtype, void* stream);
 
 /* ---- tile mapper -----------------------------------------------------------------------------
- * ms_tile_count replaces tile_overlaps_kernel (mapper/tile_mapper.py:76-86): counts[i] = number
- * of tiles of the (image_w x image_h, already padded to the tile size) grid that pass the
+ * ms_tile_count replaces tile_overlaps_kernel (mapper/tile_mapper.py:76-86): counts[j] = number
+ * of tiles (for gaussian order[j], or j when order is NULL) of the (image_w x image_h, already padded to the tile size) grid that pass the
  * OBB-vs-tile test, restricted to tile rows [tile_row_begin, tile_row_end) (multi-GPU strips;
  * pass 0 and a huge value for the whole image).  points7 is float. */
-int ms_tile_count(const float* points7, int64_t v, int image_w, int image_h, int tile_size,
-                  float alpha_threshold, int tile_row_begin, int tile_row_end,
+int ms_tile_count(const float* points7, const int32_t* order, int64_t v, int image_w, int image_h,
+                  int tile_size, float alpha_threshold, int tile_row_begin, int tile_row_end,
                   int32_t* out_counts, void* stream);
+
+/* Depth pre-sort keys (new design, replaces 2/3 of the reference's 48-bit key sort,
+ * tile_mapper.py:156): out_keys[i] = float_bits(depth[i]) (or the 16 bit quantisation of
+ * make_sort_key, tile_mapper.py:55-61, when depth16 != 0), out_values[i] = i.  Stable-sorting these
+ * pairs yields `order`, the depth order with ties by point index; ms_tile_count / ms_tile_emit then
+ * visit the gaussians in that order (counts[j] / keys of gaussian order[j]) so that a stable sort on
+ * the TILE ID alone (key_mode 2) reproduces the reference's (tile, depth, point) order. */
+int ms_depth_sort_keys(const float* depth, int64_t v, int depth16, uint32_t* out_keys,
+                       int32_t* out_values, void* stream);
 
 /* cuda_lib.full_cumsum (cuda_lib/full_cumsum.cu:17-67): exclusive scan of n int32 into out[0..n],
  * out[n] = total.  If total_host is not NULL it must be pinned, device-visible host memory and
@@ -124,12 +133,14 @@ int ms_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* t
                           void* tmp, size_t* tmp_bytes, void* stream);
 
 /* generate_sort_keys_kernel + make_sort_key (tile_mapper.py:36-66,115-146): for every passing
- * tile writes key and value at cum[i]++.  key_bytes 8: (tile_id << 32) | float_bits(depth);
- * key_bytes 4 (use_depth16): (tile_id << 16) | u16(clamp(depth,0,1)*65535).  value = point index.
- * tile_id = tx + ty * (image_w / tile_size) — NOT limited to 16 bits for 8-byte keys. */
-int ms_tile_emit(const float* points7, const float* depth, const int32_t* cum, int64_t v,
-                 int image_w, int image_h, int tile_size, float alpha_threshold,
-                 int tile_row_begin, int tile_row_end, int key_bytes,
+ * tile of gaussian p = order[j] (or j) writes key and value = p at cum[j]++.
+ * key_mode 0: u64 (tile_id << 32) | float_bits(depth[p]);  key_mode 1 (use_depth16): u32
+ * (tile_id << 16) | u16(clamp(depth[p],0,1)*65535);  key_mode 2: u32 tile_id only (depth may be
+ * NULL; requires `order` = depth order for a depth-sorted result).
+ * tile_id = tx + ty * (image_w / tile_size) — NOT limited to 16 bits for modes 0 and 2. */
+int ms_tile_emit(const float* points7, const float* depth, const int32_t* order, const int32_t* cum,
+                 int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold,
+                 int tile_row_begin, int tile_row_end, int key_mode,
                  void* out_keys, int32_t* out_values, void* stream);
 
 /* cuda_lib.radix_sort_pairs (cuda_lib/radix_sort_pairs.cu:8-70 = cub::DeviceRadixSort::SortPairs):

@@ -16,12 +16,13 @@ __device__ __forceinline__ void load_point7(const float* __restrict__ points, in
 }
 
 __global__ void __launch_bounds__(256)
-tile_count_kernel(const float* __restrict__ points, int64_t v, int image_w, int image_h, int tile_size,
-                  float alpha_threshold, int row_begin, int row_end, int32_t* __restrict__ counts) {
+tile_count_kernel(const float* __restrict__ points, const int32_t* __restrict__ order, int64_t v, int image_w,
+                  int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
+                  int32_t* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
   float g[7];
-  load_point7(points, i, g);
+  load_point7(points, order ? (int64_t)order[i] : i, g);
   const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
   int count = 0;
   for (int tv = 0; tv < q.span_y; ++tv) {
@@ -33,27 +34,29 @@ tile_count_kernel(const float* __restrict__ points, int64_t v, int image_w, int 
   counts[i] = count;
 }
 
-template <typename KeyT, bool DEPTH16>
+// MODE 0: key = tile_id << 32 | float_bits(depth)   (tile_mapper.py:36-42)
+// MODE 1: key = tile_id << 16 | u16(clamp(depth, 0, 1) * 65535)   (tile_mapper.py:55-61)
+// MODE 2: key = tile_id only — gaussians are visited in depth order (`order`), so a STABLE sort by
+//         tile alone reproduces the (tile, depth, point) order with a third of the radix passes
+template <typename KeyT, int MODE>
 __global__ void __launch_bounds__(256)
 tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ depth,
-                 const int32_t* __restrict__ cum, int64_t v, int image_w, int image_h, int tile_size,
-                 float alpha_threshold, int row_begin, int row_end, KeyT* __restrict__ keys,
-                 int32_t* __restrict__ values) {
+                 const int32_t* __restrict__ order, const int32_t* __restrict__ cum, int64_t v,
+                 int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
+                 int row_end, KeyT* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
+  const int64_t src = order ? (int64_t)order[i] : i;
   float g[7];
-  load_point7(points, i, g);
+  load_point7(points, src, g);
   const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
   const int tiles_wide = image_w / tile_size;
-  const float d = depth[i];
-  KeyT depth_key;
-  if (DEPTH16) {
-    // tile_mapper.py:55-61: clamp(depth, 0, 1) * 65535 truncated to an integer
-    const float c = fminf(fmaxf(d, 0.0f), 1.0f);
+  KeyT depth_key = 0;
+  if (MODE == 1) {
+    const float c = fminf(fmaxf(depth[src], 0.0f), 1.0f);
     depth_key = (KeyT)(uint32_t)(c * 65535.0f);
-  } else {
-    // tile_mapper.py:36-42: non-negative float bits keep their order as unsigned integers
-    depth_key = (KeyT)__float_as_uint(d);
+  } else if (MODE == 0) {
+    depth_key = (KeyT)__float_as_uint(depth[src]);   // non-negative float bits keep their order
   }
   int64_t o = cum[i];
   // same (x outer, y inner) order as ti.grouped(ti.ndrange(span.x, span.y)); the order within
@@ -64,19 +67,41 @@ tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ dep
       if (ty < row_begin || ty >= row_end) continue;
       if (obb_test_tile(q, tu, tv, tile_size)) {
         const int64_t tile_id = (int64_t)(q.min_tile_x + tu) + (int64_t)ty * tiles_wide;
-        keys[o] = DEPTH16 ? (KeyT)(depth_key | ((KeyT)tile_id << 16)) : (KeyT)(depth_key | ((KeyT)tile_id << 32));
-        values[o] = (int32_t)i;
+        keys[o] = MODE == 2 ? (KeyT)tile_id
+                            : (MODE == 1 ? (KeyT)(depth_key | ((KeyT)tile_id << 16)) : (KeyT)(depth_key | ((KeyT)tile_id << 32)));
+        values[o] = (int32_t)src;
         ++o;
       }
     }
   }
 }
 
+// 32 bit sort keys of the depth pre-sort: float bits (non-negative depths) or the 16 bit quantisation
+__global__ void __launch_bounds__(256)
+depth_keys_kernel(const float* __restrict__ depth, int64_t v, int depth16, uint32_t* __restrict__ keys,
+                  int32_t* __restrict__ values) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v) return;
+  const float d = depth[i];
+  keys[i] = depth16 ? (uint32_t)(fminf(fmaxf(d, 0.0f), 1.0f) * 65535.0f) : __float_as_uint(d);
+  values[i] = (int32_t)i;
+}
+
 }  // namespace ms
 
 using namespace ms;
 
-extern "C" int ms_tile_count(const float* points7, int64_t v, int image_w, int image_h, int tile_size,
+extern "C" int ms_depth_sort_keys(const float* depth, int64_t v, int depth16, uint32_t* out_keys,
+                                  int32_t* out_values, void* stream) {
+  MS_CHECK_ARG(v >= 0, "v < 0");
+  if (v == 0) return 0;
+  MS_CHECK_ARG(depth && out_keys && out_values, "null pointer");
+  depth_keys_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, (hipStream_t)stream>>>(depth, v, depth16, out_keys, out_values);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_tile_count(const float* points7, const int32_t* order, int64_t v, int image_w, int image_h, int tile_size,
                              float alpha_threshold, int tile_row_begin, int tile_row_end,
                              int32_t* out_counts, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
@@ -85,34 +110,33 @@ extern "C" int ms_tile_count(const float* points7, int64_t v, int image_w, int i
   if (v == 0) return 0;
   MS_CHECK_ARG(points7 && out_counts, "null pointer");
   tile_count_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      points7, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts);
+      points7, order, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts);
   MS_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int ms_tile_emit(const float* points7, const float* depth, const int32_t* cum, int64_t v,
-                            int image_w, int image_h, int tile_size, float alpha_threshold,
-                            int tile_row_begin, int tile_row_end, int key_bytes, void* out_keys,
+extern "C" int ms_tile_emit(const float* points7, const float* depth, const int32_t* order, const int32_t* cum,
+                            int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold,
+                            int tile_row_begin, int tile_row_end, int key_mode, void* out_keys,
                             int32_t* out_values, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
-  MS_CHECK_ARG(key_bytes == 4 || key_bytes == 8, "key_bytes must be 4 or 8");
+  MS_CHECK_ARG(key_mode >= 0 && key_mode <= 2, "key_mode must be 0 (tile|depth32), 1 (tile|depth16) or 2 (tile only)");
   MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
   MS_CHECK_ARG(image_w % tile_size == 0 && image_h % tile_size == 0, "image size must be padded to the tile size");
-  if (key_bytes == 4) {
+  if (key_mode == 1) {
     const int64_t tiles = (int64_t)(image_w / tile_size) * (image_h / tile_size);
     MS_CHECK_ARG(tiles <= 65536, "use_depth16 keys hold a 16 bit tile id: too many tiles");
   }
   if (v == 0) return 0;
-  MS_CHECK_ARG(points7 && depth && cum && out_keys && out_values, "null pointer");
+  MS_CHECK_ARG(points7 && cum && out_keys && out_values, "null pointer");
+  MS_CHECK_ARG(key_mode == 2 || depth, "depth is null");
   const dim3 block(256), grid((unsigned)div_up(v, 256));
-  if (key_bytes == 8)
-    tile_emit_kernel<uint64_t, false><<<grid, block, 0, (hipStream_t)stream>>>(
-        points7, depth, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end,
-        (uint64_t*)out_keys, out_values);
-  else
-    tile_emit_kernel<uint32_t, true><<<grid, block, 0, (hipStream_t)stream>>>(
-        points7, depth, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end,
-        (uint32_t*)out_keys, out_values);
+  hipStream_t s = (hipStream_t)stream;
+#define MS_EMIT(KeyT, MODE) tile_emit_kernel<KeyT, MODE><<<grid, block, 0, s>>>(points7, depth, order, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, (KeyT*)out_keys, out_values)
+  if (key_mode == 0) MS_EMIT(uint64_t, 0);
+  else if (key_mode == 1) MS_EMIT(uint32_t, 1);
+  else MS_EMIT(uint32_t, 2);
+#undef MS_EMIT
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -204,27 +204,56 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
   }
   __syncthreads();
 
-  // digit bases: global start of this block's run of digit d + counts of earlier waves
-  for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
-    unsigned run = (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
+  // per digit: exclusive offsets of the waves inside the block (cnt[w][d] <- local start of wave w's
+  // run of digit d), the block-local start of the digit (exclusive scan over the 256 digit totals)
+  // and the global start of this block's run of the digit
+  __shared__ int s_scan[4];
+  __shared__ unsigned s_digit_local[RS_RADIX];    // block-local start of digit d
+  __shared__ unsigned s_digit_global[RS_RADIX];   // global start of this block's run of digit d
+  {
+    const int d = threadIdx.x;                    // RS_THREADS == RS_RADIX
+    unsigned total = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) total += cnt[w][d];
+    int block_total;
+    const unsigned local = (unsigned)block_exclusive_scan((int)total, s_scan, &block_total);
+    unsigned run = local;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) {
       const unsigned c = cnt[w][d];
       cnt[w][d] = run;
       run += c;
     }
+    s_digit_local[d] = local;
+    s_digit_global[d] = (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
   }
   __syncthreads();
 
+  // reorder through LDS so the global scatter is written in digit order: consecutive threads then
+  // write consecutive addresses inside each digit run (coalesced 64 B+ segments instead of one
+  // transaction per lane)
+  __shared__ KeyT s_keys[RS_TILE];
+  __shared__ int32_t s_vals[RS_TILE];
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const int64_t i = base + j * 64;
     if (i < n) {
       const unsigned d = key_digit(k[j], shift, mask);
-      const int64_t pos = (int64_t)cnt[wave][d] + rank[j];
-      keys_out[pos] = k[j];
-      vals_out[pos] = v[j];
+      const unsigned lp = cnt[wave][d] + rank[j];
+      s_keys[lp] = k[j];
+      s_vals[lp] = v[j];
     }
+  }
+  __syncthreads();
+  const int64_t block_base = (int64_t)blockIdx.x * RS_TILE;
+  const int block_items = (n - block_base) < RS_TILE ? (int)(n - block_base) : RS_TILE;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < block_items; idx += RS_THREADS) {
+    const KeyT key = s_keys[idx];
+    const unsigned d = key_digit(key, shift, mask);
+    const int64_t pos = (int64_t)s_digit_global[d] + (idx - s_digit_local[d]);
+    keys_out[pos] = key;
+    vals_out[pos] = s_vals[idx];
   }
 }
 

@@ -2,9 +2,11 @@
 
 Same interface as reference ``mapper/tile_mapper.py:204-225`` (``map_to_tiles``) and ``:20-24``
 (``pad_to_tile``).  Stages (csrc/mapper.hip, csrc/scan_sort.hip):
-OBB-vs-tile overlap count -> exclusive scan (one host read of the total K) -> key emission
-``tile_id << 32 | float_bits(depth)`` -> stable radix sort over bits [0, 32 + ceil(log2 T)) ->
-per-tile ranges.  Unlike the reference (``tile_mapper.py:177-178``) the tile id is not limited to
+depth pre-sort of the V gaussians (stable radix sort of the 32 bit depth keys) -> OBB-vs-tile overlap
+count in depth order -> exclusive scan (one host read of the total K) -> emission of (tile id, point)
+-> stable radix sort on the ceil(log2 T) tile-id bits -> per-tile ranges.  The result is the order
+of the reference's single 48-bit sort of ``tile_id << 32 | float_bits(depth)`` keys generated in
+point order (tile, depth bits, point index) at a third of the sorted bytes.  Unlike the reference (``tile_mapper.py:177-178``) the tile id is not limited to
 16 bits, so 2048x2048 @ tile 8 and 4096x4096 @ tile 16 (65536 tiles) work.
 """
 from __future__ import annotations
@@ -63,43 +65,55 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     if v == 0:
       return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
 
-    counts = torch.empty((v,), dtype=torch.int32, device=device)
-    _lib.check(lib.ms_tile_count(points.data_ptr(), v, w_pad, h_pad, tile_size, config.alpha_threshold,
-                                 row_begin, row_end, counts.data_ptr(), stream), "map_to_tiles")
+    def scratch(nbytes):
+      return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
 
+    def sort_pairs(keys_in, vals_in, key_bytes, end_bit):
+      n = keys_in.shape[0]
+      keys_out, vals_out = torch.empty_like(keys_in), torch.empty_like(vals_in)
+      nb = ctypes.c_size_t(0)
+      _lib.check(lib.ms_radix_sort_pairs(None, None, None, None, n, key_bytes, 0, end_bit, None,
+                                         ctypes.byref(nb), stream), "map_to_tiles")
+      tmp = scratch(nb.value)
+      _lib.check(lib.ms_radix_sort_pairs(keys_in.data_ptr(), vals_in.data_ptr(), keys_out.data_ptr(),
+                                         vals_out.data_ptr(), n, key_bytes, 0, end_bit, tmp.data_ptr(),
+                                         ctypes.byref(nb), stream), "map_to_tiles")
+      return keys_out, vals_out
+
+    # 1. depth pre-sort of the V gaussians (stable: ties keep point order): 32 bit keys, 4 radix
+    #    passes over V pairs (2 for depth16) instead of 4 of the 6 passes over the K overlaps
+    dkeys = torch.empty((v,), dtype=torch.int32, device=device)
+    dvals = torch.empty((v,), dtype=torch.int32, device=device)
+    _lib.check(lib.ms_depth_sort_keys(depths.data_ptr(), v, int(use_depth16), dkeys.data_ptr(),
+                                      dvals.data_ptr(), stream), "map_to_tiles")
+    _, order = sort_pairs(dkeys, dvals, 4, 16 if use_depth16 else 32)
+
+    # 2. overlap counts in depth order, exclusive scan, total K (the one host sync of the mapper)
+    counts = torch.empty((v,), dtype=torch.int32, device=device)
+    _lib.check(lib.ms_tile_count(points.data_ptr(), order.data_ptr(), v, w_pad, h_pad, tile_size,
+                                 config.alpha_threshold, row_begin, row_end, counts.data_ptr(), stream),
+               "map_to_tiles")
     cum = torch.empty((v + 1,), dtype=torch.int32, device=device)
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.ms_exclusive_scan_i32(None, v, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
-    tmp = torch.empty((max(nbytes.value, 1),), dtype=torch.uint8, device=device)
+    tmp = scratch(nbytes.value)
     _lib.check(lib.ms_exclusive_scan_i32(counts.data_ptr(), v, cum.data_ptr(), None, tmp.data_ptr(),
                                          ctypes.byref(nbytes), stream), "map_to_tiles")
-    total = int(cum[v].item())   # the one host sync of the mapper: K sizes the key buffers
-
+    total = int(cum[v].item())
     if total == 0:
       return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
 
-    key_bytes = 4 if use_depth16 else 8
-    key_dtype = torch.int32 if use_depth16 else torch.int64
-    keys = torch.empty((total,), dtype=key_dtype, device=device)
+    # 3. emit (tile id, point) in depth order; 4. STABLE sort on the tile id bits only
+    keys = torch.empty((total,), dtype=torch.int32, device=device)
     values = torch.empty((total,), dtype=torch.int32, device=device)
-    _lib.check(lib.ms_tile_emit(points.data_ptr(), depths.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
-                                tile_size, config.alpha_threshold, row_begin, row_end, key_bytes,
+    _lib.check(lib.ms_tile_emit(points.data_ptr(), None, order.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
+                                tile_size, config.alpha_threshold, row_begin, row_end, 2,
                                 keys.data_ptr(), values.data_ptr(), stream), "map_to_tiles")
-
     tile_bits = max(1, (num_tiles - 1).bit_length())
-    depth_bits = 16 if use_depth16 else 32
-    end_bit = min(depth_bits + tile_bits, key_bytes * 8)
+    keys_sorted, overlap_to_point = sort_pairs(keys, values, 4, tile_bits)
 
-    keys_sorted = torch.empty_like(keys)
-    overlap_to_point = torch.empty_like(values)
-    _lib.check(lib.ms_radix_sort_pairs(None, None, None, None, total, key_bytes, 0, end_bit, None,
-                                       ctypes.byref(nbytes), stream), "map_to_tiles")
-    tmp = torch.empty((max(nbytes.value, 1),), dtype=torch.uint8, device=device)
-    _lib.check(lib.ms_radix_sort_pairs(keys.data_ptr(), values.data_ptr(), keys_sorted.data_ptr(),
-                                       overlap_to_point.data_ptr(), total, key_bytes, 0, end_bit,
-                                       tmp.data_ptr(), ctypes.byref(nbytes), stream), "map_to_tiles")
-
-    _lib.check(lib.ms_find_ranges(keys_sorted.data_ptr(), total, key_bytes, depth_bits, num_tiles,
+    # 5. per-tile ranges
+    _lib.check(lib.ms_find_ranges(keys_sorted.data_ptr(), total, 4, 0, num_tiles,
                                   tile_ranges.data_ptr(), stream), "map_to_tiles")
     return overlap_to_point, tile_ranges
 
