@@ -115,16 +115,19 @@ int ms_sh_bwd(const void* params, const void* positions, const int64_t* indexes,
  * pass 0 and a huge value for the whole image).  points7 is float. */
 int ms_tile_count(const float* points7, const int32_t* order, int64_t v, int image_w, int image_h,
                   int tile_size, float alpha_threshold, int tile_row_begin, int tile_row_end,
-                  int32_t* out_counts, void* stream);
+                  int32_t* out_counts, float* out_ordered_points7 /* (v,7) copy in visiting order, or NULL */,
+                  void* stream);
 
 /* Depth pre-sort keys (new design, replaces 2/3 of the reference's 48-bit key sort,
  * tile_mapper.py:156): out_keys[i] = float_bits(depth[i]) (or the 16 bit quantisation of
  * make_sort_key, tile_mapper.py:55-61, when depth16 != 0), out_values[i] = i.  Stable-sorting these
  * pairs yields `order`, the depth order with ties by point index; ms_tile_count / ms_tile_emit then
  * visit the gaussians in that order (counts[j] / keys of gaussian order[j]) so that a stable sort on
- * the TILE ID alone (key_mode 2) reproduces the reference's (tile, depth, point) order. */
-int ms_depth_sort_keys(const float* depth, int64_t v, int depth16, uint32_t* out_keys,
-                       int32_t* out_values, void* stream);
+ * the TILE ID alone (key_mode 2) reproduces the reference's (tile, depth, point) order.
+ * ndc_near > 0 applies ndc_depth (torch_lib/projection.py:120-123) to the camera depth first (in
+ * double, from the depth's own dtype), fusing renderer.py:67 into the key generation. */
+int ms_depth_sort_keys(const void* depth, int64_t v, int depth16, double ndc_near, double ndc_far,
+                       uint32_t* out_keys, int32_t* out_values, int dtype, void* stream);
 
 /* cuda_lib.full_cumsum (cuda_lib/full_cumsum.cu:17-67): exclusive scan of n int32 into out[0..n],
  * out[n] = total.  If total_host is not NULL it must be pinned, device-visible host memory and
@@ -141,6 +144,7 @@ int ms_exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* t
 int ms_tile_emit(const float* points7, const float* depth, const int32_t* order, const int32_t* cum,
                  int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold,
                  int tile_row_begin, int tile_row_end, int key_mode,
+                 int points_are_ordered /* points7 is ms_tile_count's ordered copy */,
                  void* out_keys, int32_t* out_values, void* stream);
 
 /* cuda_lib.radix_sort_pairs (cuda_lib/radix_sort_pairs.cu:8-70 = cub::DeviceRadixSort::SortPairs):

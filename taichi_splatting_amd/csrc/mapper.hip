@@ -18,11 +18,15 @@ __device__ __forceinline__ void load_point7(const float* __restrict__ points, in
 __global__ void __launch_bounds__(256)
 tile_count_kernel(const float* __restrict__ points, const int32_t* __restrict__ order, int64_t v, int image_w,
                   int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
-                  int32_t* __restrict__ counts) {
+                  int32_t* __restrict__ counts, float* __restrict__ ordered_points) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
   float g[7];
   load_point7(points, order ? (int64_t)order[i] : i, g);
+  if (ordered_points) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ordered_points[i * 7 + k] = g[k];   // gathered once, re-read linearly by the emit
+  }
   const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
   int count = 0;
   for (int tv = 0; tv < q.span_y; ++tv) {
@@ -43,12 +47,12 @@ __global__ void __launch_bounds__(256)
 tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ depth,
                  const int32_t* __restrict__ order, const int32_t* __restrict__ cum, int64_t v,
                  int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
-                 int row_end, KeyT* __restrict__ keys, int32_t* __restrict__ values) {
+                 int row_end, int points_ordered, KeyT* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
   const int64_t src = order ? (int64_t)order[i] : i;
   float g[7];
-  load_point7(points, src, g);
+  load_point7(points, points_ordered ? i : src, g);
   const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
   const int tiles_wide = image_w / tile_size;
   KeyT depth_key = 0;
@@ -76,13 +80,22 @@ tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ dep
   }
 }
 
-// 32 bit sort keys of the depth pre-sort: float bits (non-negative depths) or the 16 bit quantisation
+// 32 bit sort keys of the depth pre-sort: float bits (non-negative depths) or the 16 bit quantisation.
+// near_plane > 0 fuses ndc_depth (torch_lib/projection.py:120-123, renderer.py:67): evaluated in double
+// from the depth's own precision, then rounded once to the float the key is made of.
+template <typename T>
 __global__ void __launch_bounds__(256)
-depth_keys_kernel(const float* __restrict__ depth, int64_t v, int depth16, uint32_t* __restrict__ keys,
-                  int32_t* __restrict__ values) {
+depth_keys_kernel(const T* __restrict__ depth, int64_t v, int depth16, double near_plane, double far_plane,
+                  uint32_t* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
-  const float d = depth[i];
+  float d;
+  if (near_plane > 0.0) {
+    const double dd = (double)depth[i];
+    d = (float)(1.0 - (1.0 / dd - 1.0 / far_plane) / (1.0 / near_plane - 1.0 / far_plane));
+  } else {
+    d = (float)depth[i];
+  }
   keys[i] = depth16 ? (uint32_t)(fminf(fmaxf(d, 0.0f), 1.0f) * 65535.0f) : __float_as_uint(d);
   values[i] = (int32_t)i;
 }
@@ -91,34 +104,39 @@ depth_keys_kernel(const float* __restrict__ depth, int64_t v, int depth16, uint3
 
 using namespace ms;
 
-extern "C" int ms_depth_sort_keys(const float* depth, int64_t v, int depth16, uint32_t* out_keys,
-                                  int32_t* out_values, void* stream) {
+extern "C" int ms_depth_sort_keys(const void* depth, int64_t v, int depth16, double ndc_near, double ndc_far,
+                                  uint32_t* out_keys, int32_t* out_values, int dtype, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
+  MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
   if (v == 0) return 0;
   MS_CHECK_ARG(depth && out_keys && out_values, "null pointer");
-  depth_keys_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, (hipStream_t)stream>>>(depth, v, depth16, out_keys, out_values);
+  const dim3 grid((unsigned)div_up(v, 256)), block(256);
+  if (dtype == MS_F32)
+    depth_keys_kernel<float><<<grid, block, 0, (hipStream_t)stream>>>((const float*)depth, v, depth16, ndc_near, ndc_far, out_keys, out_values);
+  else
+    depth_keys_kernel<double><<<grid, block, 0, (hipStream_t)stream>>>((const double*)depth, v, depth16, ndc_near, ndc_far, out_keys, out_values);
   MS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int ms_tile_count(const float* points7, const int32_t* order, int64_t v, int image_w, int image_h, int tile_size,
                              float alpha_threshold, int tile_row_begin, int tile_row_end,
-                             int32_t* out_counts, void* stream) {
+                             int32_t* out_counts, float* out_ordered_points7, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
   MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
   MS_CHECK_ARG(image_w % tile_size == 0 && image_h % tile_size == 0, "image size must be padded to the tile size");
   if (v == 0) return 0;
   MS_CHECK_ARG(points7 && out_counts, "null pointer");
   tile_count_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      points7, order, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts);
+      points7, order, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts, out_ordered_points7);
   MS_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int ms_tile_emit(const float* points7, const float* depth, const int32_t* order, const int32_t* cum,
                             int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold,
-                            int tile_row_begin, int tile_row_end, int key_mode, void* out_keys,
-                            int32_t* out_values, void* stream) {
+                            int tile_row_begin, int tile_row_end, int key_mode, int points_are_ordered,
+                            void* out_keys, int32_t* out_values, void* stream) {
   MS_CHECK_ARG(v >= 0, "v < 0");
   MS_CHECK_ARG(key_mode >= 0 && key_mode <= 2, "key_mode must be 0 (tile|depth32), 1 (tile|depth16) or 2 (tile only)");
   MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
@@ -132,7 +150,7 @@ extern "C" int ms_tile_emit(const float* points7, const float* depth, const int3
   MS_CHECK_ARG(key_mode == 2 || depth, "depth is null");
   const dim3 block(256), grid((unsigned)div_up(v, 256));
   hipStream_t s = (hipStream_t)stream;
-#define MS_EMIT(KeyT, MODE) tile_emit_kernel<KeyT, MODE><<<grid, block, 0, s>>>(points7, depth, order, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, (KeyT*)out_keys, out_values)
+#define MS_EMIT(KeyT, MODE) tile_emit_kernel<KeyT, MODE><<<grid, block, 0, s>>>(points7, depth, order, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, points_are_ordered, (KeyT*)out_keys, out_values)
   if (key_mode == 0) MS_EMIT(uint64_t, 0);
   else if (key_mode == 1) MS_EMIT(uint32_t, 1);
   else MS_EMIT(uint32_t, 2);

@@ -31,10 +31,13 @@ def pad_to_tile(image_size: Tuple[Integral, Integral], tile_size: int):
 def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                        image_size: Tuple[Integral, Integral], config: RasterConfig,
                        use_depth16: bool = False,
-                       tile_rows: Optional[Tuple[int, int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                       tile_rows: Optional[Tuple[int, int]] = None,
+                       ndc_range: Optional[Tuple[float, float]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
   """``map_to_tiles`` restricted to tile rows [tile_rows[0], tile_rows[1]) (multi-GPU strips).
 
   ``tile_ranges`` is still indexed by the global tile id; tiles outside the strip are empty.
+  ``ndc_range=(near, far)``: ``depth`` holds camera depths and is converted to ndc depth inside the
+  key kernel (what ``render_projected`` does with torch ops in the reference, renderer.py:67).
   """
   lib = _lib.load()
   _lib.require_gpu(gaussians, depth)
@@ -58,7 +61,9 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
   with torch.no_grad():
     # the overlap test runs in float32 like the reference (Gaussian2D from taichi_lib.f32)
     points = gaussians.detach().to(torch.float32).contiguous()
-    depths = depth.detach().to(torch.float32).reshape(-1).contiguous()
+    depths = depth.detach().reshape(-1).contiguous()
+    if ndc_range is None or depths.dtype not in (torch.float32, torch.float64):
+      depths = depths.to(torch.float32)
     v = points.shape[0]
 
     tile_ranges = torch.zeros((*tile_shape, 2), dtype=torch.int32, device=device)
@@ -84,15 +89,17 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     #    passes over V pairs (2 for depth16) instead of 4 of the 6 passes over the K overlaps
     dkeys = torch.empty((v,), dtype=torch.int32, device=device)
     dvals = torch.empty((v,), dtype=torch.int32, device=device)
-    _lib.check(lib.ms_depth_sort_keys(depths.data_ptr(), v, int(use_depth16), dkeys.data_ptr(),
-                                      dvals.data_ptr(), stream), "map_to_tiles")
+    near, far = (0.0, 0.0) if ndc_range is None else (float(ndc_range[0]), float(ndc_range[1]))
+    _lib.check(lib.ms_depth_sort_keys(depths.data_ptr(), v, int(use_depth16), near, far, dkeys.data_ptr(),
+                                      dvals.data_ptr(), _lib.dtype_code(depths.dtype), stream), "map_to_tiles")
     _, order = sort_pairs(dkeys, dvals, 4, 16 if use_depth16 else 32)
 
     # 2. overlap counts in depth order, exclusive scan, total K (the one host sync of the mapper)
     counts = torch.empty((v,), dtype=torch.int32, device=device)
+    ordered = torch.empty((v, 7), dtype=torch.float32, device=device)
     _lib.check(lib.ms_tile_count(points.data_ptr(), order.data_ptr(), v, w_pad, h_pad, tile_size,
-                                 config.alpha_threshold, row_begin, row_end, counts.data_ptr(), stream),
-               "map_to_tiles")
+                                 config.alpha_threshold, row_begin, row_end, counts.data_ptr(),
+                                 ordered.data_ptr(), stream), "map_to_tiles")
     cum = torch.empty((v + 1,), dtype=torch.int32, device=device)
     nbytes = ctypes.c_size_t(0)
     _lib.check(lib.ms_exclusive_scan_i32(None, v, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
@@ -106,8 +113,8 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     # 3. emit (tile id, point) in depth order; 4. STABLE sort on the tile id bits only
     keys = torch.empty((total,), dtype=torch.int32, device=device)
     values = torch.empty((total,), dtype=torch.int32, device=device)
-    _lib.check(lib.ms_tile_emit(points.data_ptr(), None, order.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
-                                tile_size, config.alpha_threshold, row_begin, row_end, 2,
+    _lib.check(lib.ms_tile_emit(ordered.data_ptr(), None, order.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
+                                tile_size, config.alpha_threshold, row_begin, row_end, 2, 1,
                                 keys.data_ptr(), values.data_ptr(), stream), "map_to_tiles")
     tile_bits = max(1, (num_tiles - 1).bit_length())
     keys_sorted, overlap_to_point = sort_pairs(keys, values, 4, tile_bits)

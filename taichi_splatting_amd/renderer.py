@@ -59,11 +59,11 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
                      depths: torch.Tensor, camera_params: CameraParams, config: RasterConfig,
                      use_depth16: bool = False, render_median_depth: bool = False,
                      tile_rows: Optional[Tuple[int, int]] = None) -> Rendering:
-  ndc_depths = ndc_depth(depths.detach(), camera_params.near_plane, camera_params.far_plane)
-
+  # ndc depth (renderer.py:67) is computed inside the mapper's key kernel
   overlap_to_point, tile_overlap_ranges = map_to_tiles_strip(
-    gaussians2d, ndc_depths, image_size=camera_params.image_size, config=config,
-    use_depth16=use_depth16, tile_rows=tile_rows)
+    gaussians2d, depths.detach(), image_size=camera_params.image_size, config=config,
+    use_depth16=use_depth16, tile_rows=tile_rows,
+    ndc_range=(camera_params.near_plane, camera_params.far_plane))
 
   raster = rasterize_with_tiles(
     gaussians2d, features,

@@ -18,6 +18,9 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
       if (OP == 1) p[i] = __builtin_elementwise_fma(p[i], float2_{c1, c1}, float2_{c2, c2});
       if (OP == 2) a[i] = a[i] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[i]), 0xB1, 0xf, 0xf, true));
       if (OP == 3) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(c1), "s"(mask));
+      if (OP == 19) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(c1) : );
+      if (OP == 20) asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a[i]) : "v"(a[i]));
+      if (OP == 21) { asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(c1) : ); asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[(i+4)&7]) : "v"(c1), "v"(c2)); }
       if (OP == 10) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(c1));
       if (OP == 11) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(a[i]) : "v"(a[(i + 3) & 7]));
       if (OP == 12) a[i] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a[i]), 0x041F));
@@ -60,6 +63,7 @@ int main() {
   run<0>("v_fma_f32", out); run<1>("v_pk_fma_f32", out); run<8>("v_mul_f32", out); run<9>("v_pk_mul_f32", out);
   run<2>("v_add_f32_dpp quad_perm", out); run<5>("v_add_f32_dpp row_shr", out); run<3>("v_cndmask", out);
   run<10>("v_add_f32 (asm)", out); run<16>("v_fmac_f32 (asm)", out); run<18>("v_max_f32 (asm)", out); run<15>("v_add_f32_dpp quad (asm,indep)", out); run<17>("v_add_f32_dpp shr4 (asm,indep)", out);
+  run<19>("v_cndmask_e32 vcc (asm)", out); run<20>("v_add_dpp self-dependent", out); run<21>("cndmask_e32 + fmac pair", out);
   run<11>("v_mov_b32_dpp (asm)", out); run<12>("ds_swizzle", out); run<13>("ds_bpermute", out); run<14>("v_mul_lo_u32", out);
   run<4>("v_exp_f32", out); run<7>("v_rcp_f32", out); run<6>("v_permlane32_swap", out);
   return 0;
