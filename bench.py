@@ -180,7 +180,7 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  distributed = world > 1
+  distributed = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
   if distributed:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -205,7 +205,7 @@ def main():
   def step():
     for t in leaves:
       t.grad = None
-    if distributed:
+    if distributed and world > 1:
       render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
                         backward=not args.forward_only)
     elif args.forward_only:
@@ -250,7 +250,7 @@ def main():
                            f"{'fwd+bwd' if not args.forward_only else 'fwd'} (render_gaussians, loss=image.sum())",
                "n_gaussians": args.n, "image_size": list(cam.image_size), "tile_size": args.tile,
                "sh_degree": args.sh_degree,
-               "parallelism": f"tile-strips x{world} + all-reduce of 2D-boundary grads" if distributed else "single GPU"},
+               "parallelism": f"tile-strips x{world} + all-reduce of 2D-boundary grads" if world > 1 else "single GPU"},
   }
 
   if rank == 0 and not args.no_stages:

@@ -16,6 +16,10 @@
 //     current batch is consumed, hiding the dependent HBM/L2 gather latency behind the blend loop.
 #include "common.h"
 
+#ifndef MS_ABLATE
+#define MS_ABLATE 0
+#endif
+
 namespace ms {
 
 struct FastParams {
@@ -116,6 +120,13 @@ __device__ __forceinline__ float wave_reduce16(const float (&v)[16], bool b0, bo
   return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
 }
 
+// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf (inputs are never sNaN here)
+__device__ __forceinline__ float min_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
 
 template <int TS> struct TileGeom {
@@ -189,7 +200,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const float X = dx * q0.z + dy * q0.w;
         const float Y = dx * q1.x + dy * q1.y;
         const float g = __builtin_amdgcn_exp2f((X * X + Y * Y) * EXP2_SCALE);
-        const float a = fminf(q1.z * g, rp.clamp_max_alpha);
+        const float a = min_f32(q1.z * g, rp.clamp_max_alpha);
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
         T -= w;
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
@@ -233,13 +244,16 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   const float rcx = (float)patch_x + 4.0f, rcy = (float)patch_y + 4.0f;
   const bool in_bounds = pix_x < rp.width && pix_y < rp.height;
 
-  // per-pixel state (backward.py:97-110): T = 1 - W, R colour still to come, G = dL/dC
-  float R0 = 0.f, R1 = 0.f, R2 = 0.f, G0 = 0.f, G1 = 0.f, G2 = 0.f;
+  // per-pixel state (backward.py:97-110): T = 1 - W, G = dL/dC and RG = <R, G> where R is the colour
+  // still to come (remaining_features).  Only the inner product with G is ever used:
+  //   d(alpha) = sum_c (f_c T - R_c / (1 - alpha)) G_c = T <f, G> - <R, G> / (1 - alpha),
+  // and R -= f w becomes RG -= w <f, G>, so one scalar replaces the three R channels.
+  float G0 = 0.f, G1 = 0.f, G2 = 0.f, RG = 0.f;
   float T = 0.0f;
   if (in_bounds) {
     const int64_t p = (int64_t)pix_y * rp.width + pix_x;
-    R0 = image[p * 3 + 0]; R1 = image[p * 3 + 1]; R2 = image[p * 3 + 2];
     G0 = grad_image[p * 3 + 0]; G1 = grad_image[p * 3 + 1]; G2 = grad_image[p * 3 + 2];
+    RG = image[p * 3 + 0] * G0 + image[p * 3 + 1] * G1 + image[p * 3 + 2] * G2;
     T = 1.0f;
   }
 
@@ -304,12 +318,13 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const bool active = (a_raw > rp.alpha_threshold) && (T > rp.one_minus_saturate);
 
         if (__ballot(active) != 0) {
-          const float a = fminf(a_raw, rp.clamp_max_alpha);
+          const float a = min_f32(a_raw, rp.clamp_max_alpha);
           const float w = active ? a * T : 0.0f;
           const float inv = __builtin_amdgcn_rcpf(1.0f - a);
-          R0 -= f0 * w; R1 -= f1 * w; R2 -= f2 * w;
-          // d(alpha): sum_c (f_c T - R_c / (1 - alpha)) G_c  (backward.py:171-175), T before the update
-          float ag = (f0 * T - R0 * inv) * G0 + (f1 * T - R1 * inv) * G1 + (f2 * T - R2 * inv) * G2;
+          const float fG = f0 * G0 + f1 * G1 + f2 * G2;
+          RG -= w * fG;
+          // d(alpha) = T <f, G> - <R, G> / (1 - alpha)  (backward.py:171-175), T before the update
+          float ag = T * fG - RG * inv;
           ag = active ? ag : 0.0f;
           T -= w;
           const float aag = alpha_pt * ag;            // straight-through clamp (backward.py:158-163)
@@ -335,8 +350,16 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
           }
           v[12] = 0.f; v[13] = 0.f; v[14] = 0.f; v[15] = 0.f;
 
+#if MS_ABLATE == 1   /* profiling only: no cross-lane reduction */
+          const float total = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] + v[8] + v[9];
+#else
           const float total = wave_reduce16(v, b0, b1);
+#endif
+#if MS_ABLATE == 2   /* profiling only: no atomic commit */
+          if (tgt && total == 123.456f) {
+#else
           if (tgt) {
+#endif
             const unsigned id = (unsigned)s_id[r + b];
             atomic_add_noret(tgt + (size_t)(id * tgt_stride), total);
           }
