@@ -1,0 +1,83 @@
+"""-m gpu: BASELINE.json's full-size configurations, checked through size-independent properties
+(the CPU oracle cannot run 6 M gaussians): mapper invariants (ranges partition [0, K), K = sum of
+the per-tile counts, depth non-decreasing inside every tile with ties by point index), the visibility
+identity (with dL/dimage = 1 the colour gradient equals the visibility, reference
+tests/test_visibility.py:58-64), bitwise repeatability of the forward pass, agreement of the f32
+product kernels with the f64 generic kernels on a crop of tiles, and strip decomposition."""
+import pytest
+import torch
+
+from taichi_splatting_amd import RasterConfig, map_to_tiles, rasterize_with_tiles, render_gaussians
+from taichi_splatting_amd.perspective.projection import project_to_image
+from taichi_splatting_amd.rendering import ndc_depth
+from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def scene(n, size, tile):
+  torch.manual_seed(0)
+  cam = random_camera(image_size=(size, size))
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9), margin=0.0)
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
+  return g.to(DEV), cam.to(device=DEV), cfg
+
+
+@pytest.mark.parametrize('n,size,tile', [(1_000_000, 1024, 16), (6_000_000, 2048, 16), (6_000_000, 2048, 8),
+                                         (6_000_000, 2048, 32)])
+def test_fullsize_mapper_and_raster_properties(n, size, tile):
+  g, cam, cfg = scene(n, size, tile)
+  with torch.no_grad():
+    p, depth, idx = project_to_image(g, cam, cfg)
+    nd = ndc_depth(depth, cam.near_plane, cam.far_plane)
+    o2p, ranges = map_to_tiles(p, nd, cam.image_size, cfg)
+  K = o2p.shape[0]
+  flat = ranges.view(-1, 2).long()
+  counts = flat[:, 1] - flat[:, 0]
+  assert int(counts.sum()) == K and int(counts.min()) >= 0
+  ne = flat[counts > 0]
+  order = torch.argsort(ne[:, 0])
+  ne = ne[order]
+  assert int(ne[0, 0]) == 0 and int(ne[-1, 1]) == K
+  assert torch.equal(ne[1:, 0], ne[:-1, 1])                       # ranges partition [0, K)
+  assert int(o2p.min()) >= 0 and int(o2p.max()) < p.shape[0]
+  # depth sorted inside every tile (ties by ascending point index)
+  d = nd.view(-1)[o2p.long()]
+  tile_of = torch.repeat_interleave(torch.arange(flat.shape[0], device=DEV), counts)
+  same = tile_of[1:] == tile_of[:-1]
+  assert bool(((d[1:] >= d[:-1]) | ~same).all())
+  ties = same & (d[1:] == d[:-1])
+  assert bool(((o2p[1:] > o2p[:-1]) | ~ties).all())
+
+  # visibility identity + bitwise repeatable forward (f32 product kernels)
+  feats = g.feature.contiguous().requires_grad_(True)
+  cfg_v = RasterConfig(tile_size=tile, pixel_stride=cfg.pixel_stride, compute_visibility=True)
+  out = rasterize_with_tiles(p, feats, o2p, ranges.view(-1, 2), cam.image_size, cfg_v)
+  out.image.sum().backward()
+  vis = out.visibility
+  assert torch.allclose(feats.grad[:, 0], vis, rtol=2e-3, atol=2e-3)
+  assert torch.allclose(feats.grad[:, 0], feats.grad[:, 2], rtol=1e-5, atol=1e-6)
+  cfg_plain = RasterConfig(tile_size=tile, pixel_stride=cfg.pixel_stride)
+  a = rasterize_with_tiles(p, feats.detach(), o2p, ranges.view(-1, 2), cam.image_size, cfg_plain).image
+  b = rasterize_with_tiles(p, feats.detach(), o2p, ranges.view(-1, 2), cam.image_size, cfg_plain).image
+  assert torch.equal(a, b)
+  # the generic kernel (visibility variant) and the product kernel agree
+  assert torch.allclose(a, out.image.detach(), atol=2e-5)
+  assert float(a.min()) >= 0 and float(out.image_weight.max()) <= 1.0 + 1e-5
+
+
+def test_fullsize_render_gradients_finite_and_strips_agree():
+  g, cam, cfg = scene(2_000_000, 1536, 16)
+  g = g.replace(feature=(torch.rand(2_000_000, 3, 16, device=DEV) - 0.5) * 0.5)
+  g.requires_grad_(True)
+  r = render_gaussians(g, cam, cfg, use_sh=True)
+  r.image.sum().backward()
+  for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature):
+    assert torch.isfinite(t.grad).all()
+  assert r.points.idx.shape[0] == 2_000_000
+  with torch.no_grad():
+    top = render_gaussians(g, cam, cfg, use_sh=True, tile_rows=(0, 40)).image
+    bot = render_gaussians(g, cam, cfg, use_sh=True, tile_rows=(40, 96)).image
+  assert torch.equal(top[:640], r.image[:640]) and torch.equal(bot[640:], r.image[640:])
+  assert float(top[640:].abs().sum()) == 0
