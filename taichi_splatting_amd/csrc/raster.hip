@@ -16,6 +16,9 @@
 //
 // Semantics follow rasterizer/forward.py:39-135 and rasterizer/backward.py:97-224, with the
 // corrected in-group loop bound.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace ms {
@@ -503,6 +506,27 @@ bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ra
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
 
+// sub-patch edition of the product kernels (four splats per wave instruction): raster_sub.hip
+bool ms_raster_fwd_sub(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                       int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
+                       int num_tiles, hipStream_t s);
+bool ms_raster_bwd_sub(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                       const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
+                       void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
+
+// MS_RASTER_KERNEL=sub selects the experimental sub-patch kernels of raster_sub.hip (four splats per wave
+// instruction, one per 4x4 sub-patch).  They execute 0.67x the VALU instructions of the default
+// one-splat-per-wave kernels (raster_fast.hip) but commit gradients per (sub-patch, splat): the LDS
+// float atomics that pre-aggregate them cost ~34 LDS cycles per ds_add_f32 and make the backward
+// LDS-bound — config D: forward 0.78 vs 0.74 ms, backward 2.96 vs 2.93 ms — so they are not the default.
+static bool use_subpatch_kernels() {
+  static const int mode = [] {
+    const char* e = getenv("MS_RASTER_KERNEL");
+    return (e && strcmp(e, "sub") == 0) ? 1 : 0;
+  }();
+  return mode == 1;
+}
+
 static int check_raster_common(const ms_raster_config* cfg, int w, int h, int f, int dtype, int* row_begin,
                                int* row_end, const char* fn) {
   if (!cfg) { set_error("%s: cfg is null", fn); return MS_ERR_BAD_ARG; }
@@ -535,8 +559,12 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending &&
       !(cfg->compute_visibility && out_visibility)) {
-    if (ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                           out_alpha, tile_row_begin, num_tiles, s)) {
+    const bool ok = use_subpatch_kernels()
+        ? ms_raster_fwd_sub(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
+                            out_alpha, tile_row_begin, num_tiles, s)
+        : ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
+                             out_alpha, tile_row_begin, num_tiles, s);
+    if (ok) {
       MS_CHECK_LAUNCH();
       return 0;
     }
@@ -568,8 +596,12 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MS_F32 && f == 3 && !cfg->antialias) {
-    if (ms_raster_bwd_fast(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
-                           cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)) {
+    const bool ok = use_subpatch_kernels()
+        ? ms_raster_bwd_sub(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
+                            cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)
+        : ms_raster_bwd_fast(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
+                             cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s);
+    if (ok) {
       MS_CHECK_LAUNCH();
       return 0;
     }

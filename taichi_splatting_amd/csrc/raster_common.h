@@ -1,0 +1,126 @@
+// raster_common.h — pieces shared by the product raster kernels (raster_fast.hip, raster_sub.hip):
+// kernel parameters, the two-deep gather pipeline's raw record, the LDS blend / cull records, the
+// conservative rectangle-vs-contribution-ellipse test and the wave64 halving butterfly.
+#pragma once
+#include "common.h"
+
+namespace ms {
+
+struct FastParams {
+  int width, height, tiles_wide, tile_begin;
+  float clamp_max_alpha, alpha_threshold, one_minus_saturate;
+};
+
+// raw per-splat data in flight between the gather and the LDS write (one batch ahead)
+struct Raw {
+  float g[7];
+  float f[3];
+  int id;
+};
+
+__device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const float* __restrict__ feats, int id) {
+  Raw r;
+  const float* g = points + (int64_t)id * 7;
+  const float* f = feats + (int64_t)id * 3;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) r.g[k] = g[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.f[k] = f[k];
+  r.id = id;
+  return r;
+}
+
+// LDS records of one splat: blend record [mx my A B] [C D alpha f0] [f1 f2 isx isy] and cull record
+// [cx cy ex ey] [A' B' C' D'] (inverse basis divided by the cutoff radius)
+__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull) {
+  const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
+  const float isx = 1.0f / sx, isy = 1.0f / sy;
+  const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
+  rec[0] = make_float4(mx, my, A, B);
+  rec[1] = make_float4(C, D, alpha, r.f[0]);
+  rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
+  // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
+  // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
+  const float gs = sqrtf(2.0f * logf(alpha / alpha_threshold)) * 1.001f;
+  const float v1x = ax * sx * gs, v1y = ay * sx * gs, v2x = -ay * sy * gs, v2y = ax * sy * gs;
+  cull[0] = make_float4(mx, my, sqrtf(v1x * v1x + v2x * v2x) + 0.01f, sqrtf(v1y * v1y + v2y * v2y) + 0.01f);
+  const float igs = 1.0f / gs;
+  cull[1] = make_float4(A * igs, B * igs, C * igs, D * igs);
+}
+
+// does the splat's contribution region possibly touch the rectangle of pixel centres with centre
+// (rcx, rcy) and half size h (3.5 for an 8x8 patch, 1.5 for a 4x4 sub-patch)?  Conservative: false
+// only if provably no pixel of the rectangle passes alpha * g > threshold.
+__device__ __forceinline__ bool rect_hit(const float4 c0, const float4 c1, float rcx, float rcy, float h) {
+  const float dx = rcx - c0.x, dy = rcy - c0.y;   // rectangle centre relative to the mean
+  // rectangle axes: |d| <= extent + h
+  bool hit = (fabsf(dx) <= c0.z + h) && (fabsf(dy) <= c0.w + h);
+  // ellipse axes (unit circle in the normalised frame): |c| - e <= 1 (+ margin)
+  const float p1 = c1.x * dx + c1.y * dy, e1 = (fabsf(c1.x) + fabsf(c1.y)) * h;
+  const float p2 = c1.z * dx + c1.w * dy, e2 = (fabsf(c1.z) + fabsf(c1.w)) * h;
+  hit = hit && (fabsf(p1) - e1 <= 1.002f) && (fabsf(p2) - e2 <= 1.002f);
+  return hit;
+}
+
+__device__ __forceinline__ bool patch_hit(const float4 c0, const float4 c1, float rcx, float rcy) {
+  return rect_hit(c0, c1, rcx, rcy, 3.5f);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float add_dpp(float keep, float send) {
+  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
+}
+
+// index of the value whose total lane `lane` holds after wave_reduce16 (valid when (lane & 15) >= 12)
+__device__ __forceinline__ int butterfly_slot(int lane) {
+  return 4 * (2 * (lane >> 5) + ((lane >> 4) & 1)) + (lane & 3);
+}
+
+// Halving butterfly: v[0..15] -> total of value butterfly_slot(lane) in lanes with (lane & 15) >= 12.
+// Quad stages: each lane keeps half of its values and hands the rest to its partner (2 v_cndmask +
+// 1 v_add_dpp quad_perm per value pair); row_shr:4/8 finish the 16-lane rows; v_permlane16_swap /
+// v_permlane32_swap (gfx950) halve again across rows and wave halves.
+__device__ __forceinline__ float wave_reduce16(const float (&v)[16], bool b0, bool b1) {
+  float r1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
+    const float send = b0 ? v[2 * i] : v[2 * i + 1];
+    r1[i] = add_dpp<0xB1>(keep, send);                      // quad_perm:[1,0,3,2]
+  }
+  float r2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float keep = b1 ? r1[2 * j + 1] : r1[2 * j];
+    const float send = b1 ? r1[2 * j] : r1[2 * j + 1];
+    r2[j] = add_dpp<0x4E>(keep, send);                      // quad_perm:[2,3,0,1]
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r2[j] = add_dpp<0x114>(r2[j], r2[j]);                   // row_shr:4
+    r2[j] = add_dpp<0x118>(r2[j], r2[j]);                   // row_shr:8
+  }
+  const auto p0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[0]), __float_as_uint(r2[1]), false, false);
+  const auto p1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[2]), __float_as_uint(r2[3]), false, false);
+  const float s0 = __uint_as_float(p0[0]) + __uint_as_float(p0[1]);
+  const float s1 = __uint_as_float(p1[0]) + __uint_as_float(p1[1]);
+  const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+  return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
+}
+
+// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf (inputs are never sNaN here)
+__device__ __forceinline__ float min_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
+
+template <int TS> struct TileGeom {
+  static constexpr int THREADS = TS * TS;
+  static constexpr int BATCH = THREADS < 256 ? THREADS : 256;
+  static constexpr int WAVES_WIDE = TS / 8;
+};
+
+}  // namespace ms

@@ -229,3 +229,38 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
     rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
     assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
     assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
+
+
+def test_subpatch_kernels_match_default_kernels():
+  # raster_sub.hip (MS_RASTER_KERNEL=sub) against the default product kernels, in a fresh process
+  import subprocess, sys, textwrap
+  code = textwrap.dedent('''
+    import os, sys, torch
+    sys.path.insert(0, os.getcwd())
+    from taichi_splatting_amd import RasterConfig, rasterize_with_tiles, map_to_tiles
+    from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+    from taichi_splatting_amd.testing import random_2d_gaussians
+    torch.manual_seed(0)
+    size = (500, 300)
+    cfg = RasterConfig(compute_point_heuristic=True)
+    g = random_2d_gaussians(60000, size, scale_factor=1.2).to('cuda:0')
+    p = project_gaussians2d(g).requires_grad_(True); f = g.feature.clone().requires_grad_(True)
+    o2p, ranges = map_to_tiles(p, g.depths, size, cfg)
+    out = rasterize_with_tiles(p, f, o2p, ranges.view(-1, 2), size, cfg)
+    torch.manual_seed(1)
+    (out.image * torch.randn_like(out.image)).sum().backward()
+    torch.save(dict(image=out.image.detach().cpu(), gp=p.grad.cpu(), gf=f.grad.cpu(), h=out.point_heuristic.cpu()), sys.argv[1])
+  ''')
+  import tempfile, os
+  with tempfile.TemporaryDirectory() as d:
+    res = {}
+    for mode in ('patch', 'sub'):
+      path = os.path.join(d, mode + '.pt')
+      env = dict(os.environ, MS_RASTER_KERNEL=mode)
+      subprocess.run([sys.executable, '-c', code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+      res[mode] = torch.load(path)
+  a, b = res['patch'], res['sub']
+  assert torch.allclose(a['image'], b['image'], atol=2e-6)
+  for k in ('gp', 'gf', 'h'):
+    scale = a[k].abs().max().item()
+    assert (a[k] - b[k]).abs().max() < 1e-4 * scale + 1e-6, k
