@@ -186,6 +186,17 @@ int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile
                   void* grad_points7, void* grad_features, void* point_heuristic,
                   int tile_row_begin, int tile_row_end, int dtype, void* stream);
 
+/* ---- optimiser step ------------------------------------------------------------
+ * Moment update of the fractional (visibility-weighted) Adam (kind 0, optim/fractional_adam.py:8-86)
+ * and LaProp (kind 1, optim/fractional_laprop.py:8-86) for the m_count visible points listed in
+ * indexes: reads grad[idx] (N,D), the per-point step weight (m_count) and total_weight[idx] (N),
+ * updates m (N,D) and v ((N,D), or (N,) when vector != 0: one second moment per point from the
+ * squared gradient norm) in place and writes lr_step (m_count, D), float32. */
+int ms_fractional_step(int kind, int vector, float* lr_step, const int64_t* indexes,
+                       const float* weight, float* m, float* v, const float* total_weight,
+                       const float* grad, int64_t m_count, int d, float lr, float beta1,
+                       float beta2, float eps, int bias_correction, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,4 +18,4 @@ Parity status (see DESIGN.md "Oracle"):
 
 Each function cites the reference file:line (relative to /root/reference/taichi_splatting) it follows.
 """
-from . import projection, sh, mapper, raster, render  # noqa: F401
+from . import projection, sh, mapper, raster, render, optim  # noqa: F401

@@ -14,6 +14,7 @@ from .spherical_harmonics import evaluate_sh_at
 from . import perspective
 from . import cuda_lib
 from . import cuda_lib as hip_lib
+from . import optim
 from .perspective import CameraParams
 from .taichi_queue import TaichiQueue, taichi_queue, queued
 
@@ -38,7 +39,8 @@ def install_as_taichi_splatting():
   for sub in ('data_types', 'renderer', 'rendering', 'taichi_queue', 'spherical_harmonics',
               'indexed_spherical_harmonics', 'perspective', 'perspective.params',
               'perspective.projection', 'mapper', 'mapper.tile_mapper', 'rasterizer',
-              'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d'):
+              'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'optim', 'optim.fractional',
+              'optim.visibility_aware', 'optim.parameter_class', 'optim.autograd', 'optim.util'):
     mod = importlib.import_module(f'{__name__}.{sub}')
     sys.modules.setdefault(f'taichi_splatting.{sub}', mod)
   return me

@@ -55,6 +55,7 @@ SIGNATURES = {
   'ms_radix_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p, POINTER(c_size_t), c_void_p]),
   'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
   'ms_find_ranges': (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
+  'ms_fractional_step': (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
   'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
 }

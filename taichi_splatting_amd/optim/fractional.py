@@ -1,0 +1,163 @@
+"""Fractional (per-point weighted) Adam / LaProp and their sparse variants.
+
+Same classes, arguments and update rule as reference ``optim/fractional.py:113-230``; the per-point
+moment update (``fractional_adam.py`` / ``fractional_laprop.py`` Taichi kernels) is the gfx950 kernel
+``ms_fractional_step`` (csrc/optim.hip) reached through the C-ABI.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+from .util import get_scalar_state, get_total_weight, get_vector_state
+
+ADAM, LAPROP = 0, 1
+
+
+@dataclass
+class Group:
+  name: str
+  type: str
+  param: torch.Tensor
+  grad: Optional[torch.Tensor]
+  state: dict
+  lr: float
+  betas: Tuple[float, float]
+  eps: float
+  bias_correction: bool
+  clip: Optional[float]
+  mask_lr: Optional[torch.Tensor]
+  point_lr: Optional[torch.Tensor]
+
+  @property
+  def num_points(self):
+    return self.param.shape[0]
+
+
+def make_group(group, state) -> Group:
+  n = len(group["params"])
+  assert n == 1, f"expected 1 tensor in group {group['name']}, got {n}"
+  params = group["params"][0]
+  state = state[params]
+  return Group(
+    name=group["name"], type=group["type"],
+    param=params.view(params.shape[0], -1),
+    grad=params.grad.view(params.shape[0], -1) if params.grad is not None else None,
+    state=state, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+    bias_correction=group["bias_correction"], clip=group.get("clip", None),
+    mask_lr=group["mask_lr"], point_lr=group["point_lr"])
+
+
+def fractional_step(kind: int, vector: bool, lr_step, indexes, weight, m, v, total_weight, grad, lr,
+                    betas, eps, bias_correction):
+  """Launch ``ms_fractional_step``: updates m, v in place, writes lr_step (M, D)."""
+  lib = _lib.load()
+  _lib.require_gpu(lr_step, indexes, weight, m, v, total_weight, grad)
+  for t in (lr_step, weight, m, v, total_weight, grad):
+    assert t.dtype == torch.float32 and t.is_contiguous(), "fractional optimisers run in contiguous float32"
+  assert indexes.dtype == torch.int64 and indexes.is_contiguous()
+  _lib.check(lib.ms_fractional_step(kind, int(vector), lr_step.data_ptr(), indexes.data_ptr(), weight.data_ptr(),
+                                    m.data_ptr(), v.data_ptr(), total_weight.data_ptr(), grad.data_ptr(),
+                                    indexes.shape[0], lr_step.shape[1], float(lr), float(betas[0]), float(betas[1]),
+                                    float(eps), int(bias_correction), _lib.current_stream(grad.device)),
+             "fractional optimizer step")
+
+
+def weighted_step(group: Group, visible_weight: torch.Tensor, visible_indexes: torch.Tensor,
+                  total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None):
+  """reference optim/fractional.py:108-156"""
+  if group.type in ["vector", "local_vector"]:
+    m, v = get_vector_state(group.state, group.param)
+    vector = True
+  elif group.type == "scalar":
+    m, v = get_scalar_state(group.state, group.param)
+    vector = False
+  else:
+    raise ValueError(f"unknown group type {group.type}")
+
+  grad = group.grad
+  if group.type == "local_vector":
+    assert basis is not None, "basis is required for local_vector optimizer"
+    inv_basis = torch.linalg.inv(basis)
+    grad[visible_indexes] = torch.einsum('bij,bj->bi', inv_basis, grad[visible_indexes])
+
+  lr_step = group.param.new_zeros(visible_indexes.shape[0], group.param.shape[1])
+  fractional_step(kind, vector, lr_step, visible_indexes.contiguous(), visible_weight.contiguous(), m, v,
+                  total_weight, grad.contiguous(), group.lr, group.betas, group.eps, group.bias_correction)
+
+  if group.clip is not None:
+    max_step = group.lr * group.clip
+    lr_step.clamp_(-max_step, max_step)
+  if group.type == "local_vector":
+    lr_step = torch.einsum('bij,bj->bi', basis, lr_step)
+  if group.mask_lr is not None:
+    lr_step *= group.mask_lr.view(-1).unsqueeze(0)
+  if group.point_lr is not None:     # per row learning rate
+    lr_step *= group.point_lr[visible_indexes].unsqueeze(1)
+
+  lr_step[~lr_step.isfinite()] = 0.0
+  return lr_step
+
+
+def saturate(x: torch.Tensor):
+  return 1 - 1 / torch.exp(2 * x)
+
+
+class FractionalOpt(torch.optim.Optimizer):
+  def __init__(self, kind: int, param_groups, lr=0.001, betas=(0.9, 0.999), eps=1e-16,
+               bias_correction=True, clip: Optional[float] = None):
+    assert lr > 0, f"Invalid learning rate: {lr}"
+    assert eps > 0, f"Invalid epsilon: {eps}"
+    assert 0.0 <= betas[0] < 1.0, f"Invalid beta1: {betas[0]}"
+    assert 0.0 <= betas[1] < 1.0, f"Invalid beta2: {betas[1]}"
+    defaults = dict(lr=lr, betas=betas, eps=eps, mask_lr=None, point_lr=None, type="scalar",
+                    bias_correction=bias_correction, clip=clip)
+    self.kind = kind
+    super().__init__(param_groups, defaults)
+
+  @torch.no_grad()
+  def step(self, indexes: torch.Tensor, weight: torch.Tensor, basis: Optional[torch.Tensor] = None):
+    assert weight.shape == indexes.shape, f"shape mismatch {weight.shape} != {indexes.shape}"
+    groups = [make_group(group, self.state) for group in self.param_groups]
+    n = groups[0].param.shape[0]
+
+    total_weight = get_total_weight(groups[0].state, n, device=weight.device)
+    total_weight[indexes] += weight
+
+    for group in groups:
+      if group.grad is None:
+        continue
+      assert group.num_points == n, f"param shape {group.num_points} != {n}"
+      lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis)
+      group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
+
+
+class FractionalAdam(FractionalOpt):
+  def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, bias_correction=True):
+    super().__init__(ADAM, params, lr, betas, eps, bias_correction)
+
+
+class FractionalLaProp(FractionalOpt):
+  def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, bias_correction=True):
+    super().__init__(LAPROP, params, lr, betas, eps, bias_correction)
+
+
+class SparseAdam(FractionalOpt):
+  def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, bias_correction=True):
+    super().__init__(ADAM, params, lr, betas, eps, bias_correction)
+
+  def step(self, indexes: torch.Tensor, basis: Optional[torch.Tensor] = None):
+    weight = torch.ones(indexes.shape[0], device=indexes.device, dtype=torch.float32)
+    super().step(indexes, weight, basis)
+
+
+class SparseLaProp(FractionalOpt):
+  def __init__(self, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, bias_correction=True):
+    super().__init__(LAPROP, params, lr, betas, eps, bias_correction)
+
+  def step(self, indexes: torch.Tensor, basis: Optional[torch.Tensor] = None):
+    weight = torch.ones(indexes.shape[0], device=indexes.device, dtype=torch.float32)
+    super().step(indexes, weight, basis)
