@@ -1,10 +1,14 @@
-// raster.hip — tile-based alpha compositing of sorted 2D gaussians: forward and backward.
+// raster.hip — tile-based alpha compositing of sorted 2D gaussians: generic forward / backward
+// templates (float and double, F = 1..4 channels, tile 8/16/32, plain or antialiased pdf, blending or
+// quantile render, visibility, point heuristics) and the C-ABI dispatch.  The product path (float, RGB,
+// plain pdf, blending) is dispatched to the hand-tuned kernels of raster_fast.hip; everything else —
+// in particular the float64 instantiations the reference-style gradcheck tests run — uses the
+// templates below.
 //
-// Work decomposition (gfx950, wave64):
+// Work decomposition (gfx950, wave64), shared with raster_fast.hip:
 //   * one workgroup per screen tile (tile_size^2 threads), one wavefront per 8x8 pixel patch,
-//     one lane per pixel.  The per-gaussian gradient sum of the backward pass is therefore a
-//     pure in-wave reduction (DPP row_shr / row_bcast, common.h) followed by one atomic per value
-//     from lane 63 — no LDS atomics, no cross-wave combine (the reference needs a 32-lane shuffle
+//     one lane per pixel, so the per-gaussian gradient sum of the backward pass is a pure in-wave
+//     reduction — no LDS atomics, no cross-wave combine (the reference needs a 32-lane shuffle
 //     tree + shared atomics + global atomics, rasterizer/backward.py:200-224).
 //   * the tile's depth-sorted splat list is staged through LDS in batches; the staging thread also
 //     derives the axis-aligned extent of the splat's contribution ellipse (alpha_pt * g >
@@ -19,7 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.h"
+#include "raster_common.h"
 
 namespace ms {
 
@@ -106,58 +110,9 @@ __device__ __forceinline__ T splat_pdf(const Splat<T, F>& s, T px, T py) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave64 reduction of NV per-lane values, committed with atomics.
-//
-// float: a halving butterfly.  At each of the two quad stages every lane keeps half of its values
-// and hands the other half to its partner (one v_cndmask pair + one v_add_dpp quad_perm per value
-// pair), so NV values shrink to NV/4 registers whose lane (l & 3) selects the value; row_shr:4/8
-// finish the 16-lane rows, v_permlane16_swap / v_permlane32_swap (gfx950) halve again across rows
-// and wave halves.  ~40 VALU ops for 12 values instead of 72 for twelve 6-step DPP trees, and the
-// NV totals end up in NV DISTINCT lanes, so ONE global_atomic_add_f32 instruction commits them all
-// (the reference: 32-lane shuffle tree + shared atomics + global atomics, backward.py:200-224).
+// Gradient commit of the generic kernels.  float: the halving butterfly of raster_common.h
+// (wave_reduce16: the NV totals end in NV distinct lanes, ONE global_atomic_add_f32 commits them);
 // double (test-only path): plain ds_bpermute butterflies + one atomic per value from lane 63.
-// ------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ float add_dpp(float keep, float send) {
-  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xf, 0xf, true));
-}
-
-// index of the value whose total lane `lane` holds after wave_reduce16 (valid when (lane & 15) >= 12)
-__device__ __forceinline__ int butterfly_slot(int lane) {
-  return 4 * (2 * (lane >> 5) + ((lane >> 4) & 1)) + (lane & 3);
-}
-
-// v[0..15] -> total of value butterfly_slot(lane) in the lanes with (lane & 15) >= 12
-__device__ __forceinline__ float wave_reduce16(const float (&v)[16], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-  float r1[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float keep = b0 ? v[2 * i + 1] : v[2 * i];
-    const float send = b0 ? v[2 * i] : v[2 * i + 1];
-    r1[i] = add_dpp<0xB1>(keep, send);                      // quad_perm:[1,0,3,2]
-  }
-  float r2[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float keep = b1 ? r1[2 * j + 1] : r1[2 * j];
-    const float send = b1 ? r1[2 * j] : r1[2 * j + 1];
-    r2[j] = add_dpp<0x4E>(keep, send);                      // quad_perm:[2,3,0,1]
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    r2[j] = add_dpp<0x114>(r2[j], r2[j]);                   // row_shr:4
-    r2[j] = add_dpp<0x118>(r2[j], r2[j]);                   // row_shr:8
-  }
-  // rows: (r2[0], r2[1]) and (r2[2], r2[3]) -> even rows keep the first, odd rows the second
-  const auto p0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[0]), __float_as_uint(r2[1]), false, false);
-  const auto p1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2[2]), __float_as_uint(r2[3]), false, false);
-  const float s0 = __uint_as_float(p0[0]) + __uint_as_float(p0[1]);
-  const float s1 = __uint_as_float(p1[0]) + __uint_as_float(p1[1]);
-  const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
-  return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -267,14 +222,14 @@ __device__ __forceinline__ void commit_gradients(const T (&v)[16], int32_t id, i
 
 template <>
 __device__ __forceinline__ void commit_gradients<float, 1, false>(const float (&v)[16], int32_t id, int lane, float* b, int st, float*, float*, float*) {
-  const float total = wave_reduce16(v, lane);
+  const float total = wave_reduce16(v, lane & 1, lane & 2);
   if (b) atomic_add_noret(b + (int64_t)id * st, total);
 }
 #define MS_COMMIT_F32(F, HEUR)                                                                                   \
   template <>                                                                                                    \
   __device__ __forceinline__ void commit_gradients<float, F, HEUR>(const float (&v)[16], int32_t id, int lane,   \
                                                                    float* b, int st, float*, float*, float*) {   \
-    const float total = wave_reduce16(v, lane);                                                                  \
+    const float total = wave_reduce16(v, lane & 1, lane & 2);                                                                  \
     if (b) atomic_add_noret(b + (int64_t)id * st, total);                                                        \
   }
 MS_COMMIT_F32(1, true) MS_COMMIT_F32(2, false) MS_COMMIT_F32(2, true) MS_COMMIT_F32(3, false)

@@ -96,3 +96,16 @@ def test_render_options_median_depth_and_visibility():
   r2 = render_gaussians(g.to(DEV), cam.to(device=DEV), cfg2)
   with pytest.raises(AssertionError):
     _ = r2.points.visibility
+
+
+def test_render_depth16_keys_and_strip_window():
+  size = (200, 120)
+  g, cam = make_scene(3000, size, seed=21)
+  cfg = RasterConfig()
+  full = render_gaussians(g.to(DEV), cam.to(device=DEV), cfg)
+  d16 = render_gaussians(g.to(DEV), cam.to(device=DEV), cfg, use_depth16=True)
+  # 16 bit depth quantisation only reorders splats closer than 1/65535 in ndc depth
+  assert (full.image - d16.image).abs().max() < 0.2 and (full.image - d16.image).abs().mean() < 1e-3
+  part = render_gaussians(g.to(DEV), cam.to(device=DEV), cfg, tile_rows=(2, 5))
+  assert torch.equal(part.image[32:80], full.image[32:80])
+  assert float(part.image[:32].abs().sum()) == 0 and float(part.image[80:].abs().sum()) == 0
