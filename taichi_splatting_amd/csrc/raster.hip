@@ -474,13 +474,22 @@ bool ms_raster_bwd_sub(const void* points, const void* feats, const int32_t* ran
 // one-splat-per-wave kernels (raster_fast.hip) but commit gradients per (sub-patch, splat): the LDS
 // float atomics that pre-aggregate them cost ~34 LDS cycles per ds_add_f32 and make the backward
 // LDS-bound — config D: forward 0.78 vs 0.74 ms, backward 2.96 vs 2.93 ms — so they are not the default.
-static bool use_subpatch_kernels() {
+static int raster_kernel_mode() {
   static const int mode = [] {
     const char* e = getenv("MS_RASTER_KERNEL");
-    return (e && strcmp(e, "sub") == 0) ? 1 : 0;
+    if (e && strcmp(e, "sub") == 0) return 1;
+    if (e && strcmp(e, "pairs") == 0) return 2;
+    if (e && strcmp(e, "patch") == 0) return 3;
+    return 0;
   }();
-  return mode == 1;
+  return mode;
 }
+static bool use_subpatch_kernels() { return raster_kernel_mode() == 1; }
+
+// active-pair compaction backward (raster_pairs.hip)
+bool ms_raster_bwd_pairs(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
+                         void* gp, void* gf, int row_begin, int num_tiles, hipStream_t s);
 
 static int check_raster_common(const ms_raster_config* cfg, int w, int h, int f, int dtype, int* row_begin,
                                int* row_end, const char* fn) {
@@ -550,6 +559,13 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
   const int tiles_wide = (image_w + cfg->tile_size - 1) / cfg->tile_size;
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == MS_F32 && f == 3 && !cfg->antialias && raster_kernel_mode() == 2 && !point_heuristic) {
+    if (ms_raster_bwd_pairs(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
+                            cfg, grad_points7, grad_features, tile_row_begin, num_tiles, s)) {
+      MS_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (dtype == MS_F32 && f == 3 && !cfg->antialias) {
     const bool ok = use_subpatch_kernels()
         ? ms_raster_bwd_sub(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
