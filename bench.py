@@ -41,6 +41,9 @@ def parse_args():
   p.add_argument('--seed', type=int, default=0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-stages', action='store_true')
+  p.add_argument('--mode', choices=['auto', 'single', 'sharded', 'strips'], default='auto',
+                 help='multi-GPU decomposition: sharded = gaussians by index + pixels by tile-row strip with an '
+                      'all-to-all of projected splats (default for N > 1); strips = replicated gaussians + all-reduce')
   p.add_argument('--forward-only', action='store_true')
   return p.parse_args()
 
@@ -192,21 +195,35 @@ def main():
   torch.cuda.set_device(device)
 
   from taichi_splatting_amd import RasterConfig, render_gaussians, _lib
-  from taichi_splatting_amd.distributed import render_strip_step
+  from taichi_splatting_amd.distributed import render_strip_step, render_sharded_step, shard_range
   _lib.load()
+  mode = args.mode
+  if mode == 'auto':
+    mode = 'sharded' if world > 1 else 'single'
 
   cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
   log(f"building scene n={args.n} size={args.size}")
   g, cam = make_scene(args, device)
   log("scene on device")
   use_sh = True
+  shard_begin = 0
+  if mode == 'sharded':
+    # every rank generated the same scene (same seed); it keeps only its shard of the gaussians
+    shard_begin, shard_end = shard_range(args.n, world, rank)
+    full = g
+    g = g[shard_begin:shard_end].clone().contiguous()
+    del full
+    torch.cuda.empty_cache()
   g.requires_grad_(not args.forward_only)
   leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
 
   def step():
     for t in leaves:
       t.grad = None
-    if distributed and world > 1:
+    if mode == 'sharded':
+      render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
+                          backward=not args.forward_only, index_offset=shard_begin)
+    elif mode == 'strips':
       render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
                         backward=not args.forward_only)
     elif args.forward_only:
@@ -251,10 +268,13 @@ def main():
                            f"{'fwd+bwd' if not args.forward_only else 'fwd'} (render_gaussians, loss=image.sum())",
                "n_gaussians": args.n, "image_size": list(cam.image_size), "tile_size": args.tile,
                "sh_degree": args.sh_degree,
-               "parallelism": f"tile-strips x{world} + all-reduce of 2D-boundary grads" if world > 1 else "single GPU"},
+               "parallelism": {"single": "single GPU",
+                               "sharded": f"gaussians sharded x{world} (projection/SH) + tile-row strips x{world} (map/raster), "
+                                          "all-to-all of projected splats and of their gradients",
+                               "strips": f"replicated gaussians, tile-row strips x{world}, all-reduce of 2D-boundary grads"}[mode]},
   }
 
-  if rank == 0 and not args.no_stages:
+  if rank == 0 and not args.no_stages and mode == 'single':
     g.requires_grad_(False)
     stages, V, K = stage_breakdown(g, cam, cfg, use_sh)
     log(f"stages {stages} V={V} K={K}")

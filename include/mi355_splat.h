@@ -197,6 +197,43 @@ int ms_fractional_step(int kind, int vector, float* lr_step, const int64_t* inde
                        const float* grad, int64_t m_count, int d, float lr, float beta1,
                        float beta2, float eps, int bias_correction, void* stream);
 
+/* ---- camera position ----------------------------------------------------------------------------------
+ * out_position3 = inverse(T_camera_world)[0:3, 3] for a row-major 4x4 (perspective/params.py:62-65), one
+ * launch instead of a device-side LU. */
+int ms_camera_position(const void* t_camera_world, void* out_position3, int dtype, void* stream);
+
+/* ---- multi-GPU: routing projected splats to tile-row strips -----------------------------
+ * New design, no reference counterpart (the reference renders on one GPU).  Rank r renders the tile rows
+ * [bounds[r], bounds[r+1]); a projected splat goes to every rank whose strip meets the tile-row span of
+ * the mapper's grid query (taichi_lib/grid_query.py:10-40), i.e. a stable multi-way split by destination.
+ * float32 only.
+ *
+ * ms_strip_route_blocks: number of 256-splat blocks B of the split (scratch: out_block_counts is
+ *   world x B int32).
+ * ms_strip_route_count: out_route[i] = first_rank | copies << 16; out_block_counts = per-(rank, block)
+ *   exclusive slot offsets inside the rank's bucket; out_send_counts[r] (int64, device) = splats routed
+ *   to rank r = the all-to-all split sizes.  bounds_host: world + 1 ints in host memory.
+ * ms_strip_route_pack: writes the send buffer, buckets in rank order and local index order inside a
+ *   bucket: out_rows (S, 9 + f) = [packed 2D (7) | colour (f) | depth | global id as int32 bits], global
+ *   id = (ids ? ids[i] : i) + index_offset; out_send_index[slot] = i (to sum the returned gradients).
+ * ms_strip_unpack: splits received rows into the arrays the mapper / rasterizer consume.
+ * ms_strip_return_grads: backward of the exchange on the sending side: back_rows (S, 7 + f) =
+ *   [d packed 2D | d colour] of every slot of the send buffer, summed into the zero-initialised
+ *   grad_points7 (V, 7) / grad_features (V, f) of the local splats (grad[send_index[slot]] += row);
+ *   route = out_route of ms_strip_route_count (splats with one copy are stored, not accumulated). */
+int ms_strip_route_blocks(int v);
+int ms_strip_route_count(const float* points7, int v, int image_h, int tile_size, float alpha_threshold,
+                         const int32_t* bounds_host, int world, int32_t* out_route,
+                         int32_t* out_block_counts, int64_t* out_send_counts, void* stream);
+int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
+                        const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                        const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                        float* out_rows, int64_t* out_send_index, void* stream);
+int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, float* out_features,
+                    float* out_depths, int64_t* out_ids, void* stream);
+int ms_strip_return_grads(const float* back_rows, const int64_t* send_index, const int32_t* route,
+                          int f, int64_t s, float* grad_points7, float* grad_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,11 +1,21 @@
-"""Multi-GPU rendering of ONE frame by screen-tile strips (new design; the reference is single GPU).
+"""Multi-GPU rendering of ONE frame (new design; the reference is single GPU).
 
-One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  Gaussians are
-replicated; rank r owns a contiguous strip of tile rows, maps/sorts/rasterizes only the overlaps of
-its strip, and evaluates its part of the loss on its rows of the image.  Tiles are independent in
-both raster passes, so the only exchange is the per-gaussian gradient sum: ONE all-reduce of the
-2D-boundary gradient [d packed-2D (7) | d colour (F)] = 40 B x V for RGB, after which the
-projection / SH backward runs replicated (payload 6x smaller than reducing the 3D/SH gradients).
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  Two decompositions:
+
+``render_sharded_step`` (default for N > 1) — gaussians AND pixels are sharded.  Rank r owns a
+  contiguous shard of the gaussians (its parameters, optimizer state and gradients never leave the
+  rank) and a contiguous strip of tile rows.  The per-gaussian stages (projection, SH colour and their
+  backward) run on the shard; the projected splats [packed 2D (7) | colour (F) | depth | global id]
+  = 48 B for RGB are routed with ONE variable-size all-to-all to the ranks whose strip they can
+  overlap (the mapper's own row span, so the routing is exact up to a 0.01 px slack); each rank maps /
+  sorts / rasterizes its strip; the 2D-boundary gradients travel back through the reverse all-to-all
+  and are summed into the shard.  Nothing is replicated and nothing is all-reduced: per-rank work and
+  per-rank traffic are ~1/N of the frame (plus the splats that straddle a strip boundary).
+
+``render_strip_step`` — gaussians replicated, strips of tile rows, ONE all-reduce of the 2D-boundary
+  gradient (40 B x V for RGB) before the replicated projection / SH backward.  Simple, but the
+  per-gaussian stages and the all-reduce do not shrink with N; kept for scenes that fit one GPU and
+  callers that want the full gradient on every rank.
 """
 from __future__ import annotations
 
@@ -101,3 +111,275 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
       tensors.append(features); grads.append(gf)
     torch.autograd.backward(tensors, grads)
   return rendering, loss.detach()
+
+
+# --------------------------------------------------------------------------------------------------
+# gaussian-sharded / strip-sharded rendering: all-to-all of projected splats
+# --------------------------------------------------------------------------------------------------
+
+def shard_range(n: int, world_size: int, rank: int) -> Tuple[int, int]:
+  """Contiguous index range [begin, end) of the gaussians owned by ``rank``."""
+  assert 0 <= rank < world_size
+  return (n * rank) // world_size, (n * (rank + 1)) // world_size
+
+
+def strip_bounds(tiles_high: int, world_size: int, row_weights: Optional[Sequence[float]] = None):
+  """[b_0 = 0, b_1, ..., b_world = tiles_high]: rank r renders tile rows [b_r, b_{r+1})."""
+  return [strip_rows(tiles_high, world_size, r, row_weights)[0] for r in range(world_size)] + [tiles_high]
+
+
+def splat_row_span(points7: torch.Tensor, image_size: Tuple[int, int], config: RasterConfig,
+                   slack_px: float = 0.01) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Tile-row span [lo, hi) each packed 2D gaussian can overlap: the bounds of the tile mapper's grid
+  query (csrc/splat_math.h obb_grid_query; reference taichi_lib/grid_query.py:10-40) widened by
+  ``slack_px`` so that float rounding differences can only add rows.  lo == hi == 0 for splats the
+  mapper culls (alpha below the threshold, NaN extent)."""
+  ts = float(config.tile_size)
+  tiles_high = (image_size[1] + config.tile_size - 1) // config.tile_size
+  my, ax, ay, sx, sy, alpha = (points7[:, i] for i in (1, 2, 3, 4, 5, 6))
+  gs = torch.sqrt(2.0 * torch.log(alpha / config.alpha_threshold))       # NaN when alpha < threshold
+  ey = torch.sqrt((ay * sx * gs) ** 2 + (ax * sy * gs) ** 2) + slack_px
+  ok = torch.isfinite(ey) & torch.isfinite(my)
+  lo = torch.floor((my - ey) / ts).clamp(0, tiles_high)
+  hi = torch.ceil((my + ey) / ts)
+  hi = torch.minimum(torch.maximum(hi, lo + 1), torch.full_like(hi, float(tiles_high)))
+  lo = torch.where(ok, lo, torch.zeros_like(lo)).to(torch.int64)
+  hi = torch.where(ok, hi, torch.zeros_like(hi)).to(torch.int64)
+  hi = torch.maximum(hi, lo)          # lo >= tiles_high: empty span
+  return lo, hi
+
+
+def route_to_strips(row_lo: torch.Tensor, row_hi: torch.Tensor, bounds: Sequence[int]):
+  """Routing plan, all on device and without a host synchronisation.
+
+  Returns (first_rank, copies, send_counts): splat i goes to the ``copies[i]`` consecutive ranks
+  starting at ``first_rank[i]`` (the ranks whose strip intersects [row_lo, row_hi)); ``send_counts[d]``
+  = number of splats sent to rank d."""
+  world = len(bounds) - 1
+  ends = torch.as_tensor(list(bounds[1:]), dtype=torch.int64, device=row_lo.device)
+  nonempty = row_hi > row_lo
+  first = torch.searchsorted(ends, row_lo, right=True).clamp_(max=world - 1)
+  last = torch.searchsorted(ends, (row_hi - 1).clamp_(min=0), right=True).clamp_(max=world - 1)
+  copies = torch.where(nonempty, last - first + 1, torch.zeros_like(first))
+  # splats per destination = running sum of (+1 at first, -1 after last)
+  plus = torch.bincount(first[nonempty], minlength=world + 1)
+  minus = torch.bincount(last[nonempty] + 1, minlength=world + 1)
+  send_counts = torch.cumsum(plus - minus, 0)[:world]
+  return first, copies, send_counts
+
+
+def expand_routes(first: torch.Tensor, copies: torch.Tensor, total: int):
+  """(send_index, dest) of the ``total`` routed copies, ordered by destination rank and, within a
+  destination, by local splat index (so that depth ties keep breaking by gaussian index after the
+  exchange, as in the single-GPU sort order: mapper/tile_mapper.py)."""
+  n = first.shape[0]
+  dev = first.device
+  if total == 0:
+    e = torch.empty(0, dtype=torch.int64, device=dev)
+    return e, e
+  offsets = torch.cumsum(copies, 0) - copies
+  idx = torch.repeat_interleave(torch.arange(n, device=dev), copies, output_size=total)
+  dest = first[idx] + (torch.arange(total, device=dev) - offsets[idx])
+  dest, order = torch.sort(dest, stable=True)
+  return idx[order], dest
+
+
+def _all_to_all(send: torch.Tensor, send_counts, recv_counts, group) -> torch.Tensor:
+  """``recv`` = rows received from every rank, grouped by source rank (RCCL all-to-all: unequal splits)."""
+  recv = send.new_empty((int(sum(recv_counts)),) + tuple(send.shape[1:]))
+  if dist.is_available() and dist.is_initialized():
+    dist.all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts), group=group)
+  else:
+    assert list(send_counts) == list(recv_counts)
+    recv.copy_(send)
+  return recv
+
+
+def all_to_all_via_host(send: torch.Tensor, send_counts, recv_counts, group) -> torch.Tensor:
+  """The same exchange staged through host memory (for process groups without device collectives,
+  e.g. gloo in tests: several ranks can then share one GPU)."""
+  return _all_to_all(send.cpu(), send_counts, recv_counts, group).to(send.device)
+
+
+class _StripExchange(torch.autograd.Function):
+  """(gaussians2d, features) -> the rows received for this rank's strip.  The send buffer ``rows`` was
+  packed from the same tensors (no grad); backward = reverse all-to-all of [d gaussians2d | d features]
+  + sum of the copies of each local splat."""
+
+  @staticmethod
+  def forward(ctx, gaussians2d, features, rows, send_index, route, send_counts, recv_counts, group, exchange):
+    ctx.route = route
+    ctx.send_index, ctx.send_counts, ctx.recv_counts = send_index, send_counts, recv_counts
+    ctx.group, ctx.exchange, ctx.n, ctx.f = group, exchange, gaussians2d.shape[0], features.shape[1]
+    recv = exchange(rows, send_counts, recv_counts, group)
+    g2, f2, d, ids = _split_rows(recv, ctx.f)
+    ctx.mark_non_differentiable(d, ids)
+    return g2, f2, d, ids
+
+  @staticmethod
+  def backward(ctx, grad_g2, grad_f2, _grad_d, _grad_ids):
+    m = int(sum(ctx.recv_counts))
+    dev_like = grad_g2 if grad_g2 is not None else grad_f2
+    if grad_g2 is None:
+      grad_g2 = dev_like.new_zeros((m, 7))
+    if grad_f2 is None:
+      grad_f2 = dev_like.new_zeros((m, ctx.f))
+    back = ctx.exchange(torch.cat([grad_g2, grad_f2], dim=1), ctx.recv_counts, ctx.send_counts, ctx.group)
+    if ctx.route is not None:
+      back = back.contiguous()
+      from . import _lib
+      lib = _lib.load()
+      gp, gf = back.new_zeros((ctx.n, 7)), back.new_zeros((ctx.n, ctx.f))
+      _lib.check(lib.ms_strip_return_grads(_lib.ptr(back), _lib.ptr(ctx.send_index), _lib.ptr(ctx.route), ctx.f, back.shape[0],
+                                           _lib.ptr(gp), _lib.ptr(gf), _lib.current_stream(back.device)),
+                 'ms_strip_return_grads')
+      return gp, gf, None, None, None, None, None, None, None
+    grad = back.new_zeros((ctx.n, 7 + ctx.f))
+    grad.index_add_(0, ctx.send_index, back)
+    return grad[:, :7].contiguous(), grad[:, 7:].contiguous(), None, None, None, None, None, None, None
+
+
+FORCE_TORCH_ROUTING = False      # tests: compare the HIP routing kernels with the torch formulation
+
+
+def _use_kernels(t: torch.Tensor) -> bool:
+  return t.is_cuda and t.dtype == torch.float32 and not FORCE_TORCH_ROUTING
+
+
+def _split_rows(recv: torch.Tensor, f: int):
+  """(gaussians2d, features, depths, ids) arrays of received rows [packed 2D | colour | depth | id bits]."""
+  m = recv.shape[0]
+  if _use_kernels(recv):
+    from . import _lib
+    lib = _lib.load()
+    g2, f2 = recv.new_empty((m, 7)), recv.new_empty((m, f))
+    d, ids = recv.new_empty((m,)), torch.empty((m,), dtype=torch.int64, device=recv.device)
+    _lib.check(lib.ms_strip_unpack(_lib.ptr(recv), m, f, _lib.ptr(g2), _lib.ptr(f2), _lib.ptr(d), _lib.ptr(ids),
+                                   _lib.current_stream(recv.device)), 'ms_strip_unpack')
+    return g2, f2, d, ids
+  id_type = torch.int32 if recv.dtype == torch.float32 else torch.int64
+  return (recv[:, :7].contiguous(), recv[:, 7:7 + f].contiguous(), recv[:, 7 + f].contiguous(),
+          recv[:, 8 + f].contiguous().view(id_type).to(torch.int64))
+
+
+def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths: torch.Tensor,
+                       image_size: Tuple[int, int], config: RasterConfig, bounds: Sequence[int],
+                       global_index: Optional[torch.Tensor] = None, index_offset: int = 0, group=None,
+                       exchange=_all_to_all):
+  """Route this rank's projected splats to the strips they can overlap.
+
+  Returns (gaussians2d, features, depths, global_index) of the splats RECEIVED for this rank's strip,
+  grouped by source rank and in source order; gaussians2d / features stay attached to the autograd
+  graph (the backward pass sends their gradients home and sums them per splat).  Global id of local
+  splat i = (global_index[i] if given else i) + index_offset.  ``exchange`` is the collective.
+
+  float32 device tensors take the HIP path (csrc/strip_route.hip: count / offsets / pack / unpack
+  kernels); other inputs (float64 gradcheck-style tests, CPU tensors under gloo) the equivalent torch
+  formulation below."""
+  world = len(bounds) - 1
+  n, f = gaussians2d.shape[0], features.shape[1]
+  g2d, feats, dep = gaussians2d.detach().contiguous(), features.detach().contiguous(), depths.detach().reshape(-1).contiguous()
+  kernels = _use_kernels(g2d) and feats.dtype == torch.float32 and dep.dtype == torch.float32
+  if kernels:
+    from . import _lib
+    lib = _lib.load()
+    stream = _lib.current_stream(g2d.device)
+    nb = lib.ms_strip_route_blocks(n)
+    route = torch.empty((max(n, 1),), dtype=torch.int32, device=g2d.device)
+    block_offsets = torch.empty((world * nb,), dtype=torch.int32, device=g2d.device)
+    send_counts_t = torch.empty((world,), dtype=torch.int64, device=g2d.device)
+    import ctypes
+    bounds_c = (ctypes.c_int32 * (world + 1))(*[int(b) for b in bounds])
+    _lib.check(lib.ms_strip_route_count(_lib.ptr(g2d), n, int(image_size[1]), config.tile_size,
+                                        config.alpha_threshold, ctypes.cast(bounds_c, ctypes.c_void_p), world,
+                                        _lib.ptr(route), _lib.ptr(block_offsets), _lib.ptr(send_counts_t), stream),
+               'ms_strip_route_count')
+  else:
+    lo, hi = splat_row_span(g2d, image_size, config)
+    first, copies, send_counts_t = route_to_strips(lo, hi, bounds)
+
+  # split sizes: one tiny all-to-all + ONE host synchronisation
+  recv_counts_t = exchange(send_counts_t.view(world, 1), [1] * world, [1] * world, group)
+  send_counts, recv_counts = torch.stack([send_counts_t, recv_counts_t.view(world)]).tolist()
+  total = int(sum(send_counts))
+
+  if kernels:
+    rows = g2d.new_empty((total, 9 + f))
+    send_index = torch.empty((total,), dtype=torch.int64, device=g2d.device)
+    ids = global_index.to(torch.int64).contiguous() if global_index is not None else None
+    _lib.check(lib.ms_strip_route_pack(_lib.ptr(g2d), _lib.ptr(feats), _lib.ptr(dep), _lib.ptr(ids), f, n,
+                                       world, int(index_offset), _lib.ptr(route), _lib.ptr(block_offsets),
+                                       _lib.ptr(send_counts_t), _lib.ptr(rows), _lib.ptr(send_index), stream),
+               'ms_strip_route_pack')
+  else:
+    send_index, _ = expand_routes(first, copies, total)
+    gid = (global_index if global_index is not None else torch.arange(n, device=g2d.device)) + index_offset
+    id_type = torch.int32 if g2d.dtype == torch.float32 else torch.int64        # ids travel as payload bits
+    rows = torch.cat([g2d, feats, dep.to(g2d.dtype).unsqueeze(1), gid.to(id_type).view(g2d.dtype).unsqueeze(1)],
+                     dim=1)[send_index]
+
+  g2, f2, d, gid = _StripExchange.apply(gaussians2d, features, rows, send_index, route if kernels else None,
+                                        send_counts, recv_counts, group, exchange)
+  return g2, f2, d.reshape((-1,) + tuple(depths.shape[1:])), gid
+
+
+def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
+                        loss_fn: Callable[[torch.Tensor, Tuple[int, int]], torch.Tensor],
+                        use_sh: bool = False, rank: Optional[int] = None, world_size: Optional[int] = None,
+                        group=None, backward: bool = True, index_offset: int = 0,
+                        bounds: Optional[Sequence[int]] = None, exchange=_all_to_all):
+  """One forward(+backward) step with gaussians sharded by index and pixels sharded by tile-row strip.
+
+  ``shard`` holds only this rank's gaussians (``index_offset`` = global index of its first one).
+  ``loss_fn(strip_image, (row_begin_px, row_end_px))`` returns this rank's share of the loss;
+  ``strip_image`` (row_end_px - row_begin_px, W, F) holds ONLY the strip's pixel rows (no rank ever
+  allocates or touches the full frame).  After the call ``.grad`` of the leaf tensors of ``shard`` is the complete gradient of the
+  summed loss for those gaussians.  Returns (Rendering of the strip, loss value of the strip); the
+  ``points`` of the rendering are the splats received for the strip, ``points.idx`` their global ids.
+  """
+  from .perspective.projection import project_to_image
+  from .renderer import render_projected
+  from .spherical_harmonics import evaluate_sh_at
+
+  if rank is None:
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+  if world_size is None:
+    world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+
+  gaussians2d, depths, indexes = project_to_image(shard, camera_params, config)
+  if use_sh:
+    features = evaluate_sh_at(shard.feature, shard.position.detach(), indexes, camera_params.camera_position,
+                              unique_indexes=True)
+  else:
+    features = shard.feature[indexes]
+
+  ts = config.tile_size
+  tiles_high = (camera_params.image_size[1] + ts - 1) // ts
+  if bounds is None:
+    bounds = strip_bounds(tiles_high, world_size)
+  rows = (bounds[rank], bounds[rank + 1])
+
+  g2, f2, d, gid = exchange_to_strips(gaussians2d, features, depths, camera_params.image_size, config, bounds,
+                                      global_index=indexes, index_offset=index_offset, group=group,
+                                      exchange=exchange)
+  rendering = render_projected(gid, g2, f2, d, camera_params, config, tile_rows=rows, crop_to_rows=True)
+
+  h = camera_params.image_size[1]
+  px_rows = (min(rows[0] * ts, h), min(rows[1] * ts, h))
+  loss = loss_fn(rendering.image, px_rows)
+  if backward and loss.requires_grad:
+    loss.backward()
+  return rendering, loss.detach()
+
+
+def balanced_strip_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, int], config: RasterConfig,
+                          world_size: int, group=None):
+  """Strip boundaries that equalise the number of splat centres per strip over ALL ranks' splats
+  (one small all-reduce of a per-tile-row histogram + one host sync)."""
+  ts = config.tile_size
+  tiles_high = (image_size[1] + ts - 1) // ts
+  row = torch.floor(gaussians2d[:, 1].detach() / ts).clamp(0, tiles_high - 1).to(torch.int64)
+  hist = torch.bincount(row, minlength=tiles_high).to(torch.float32)
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_reduce(hist, group=group)
+  return strip_bounds(tiles_high, world_size, hist.tolist())

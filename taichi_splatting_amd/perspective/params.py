@@ -61,7 +61,17 @@ class CameraParams:
 
   @property
   def camera_position(self):
-    T_world_camera = torch.inverse(self.T_camera_world)
+    T = self.T_camera_world
+    if T.is_cuda and not T.requires_grad and T.dtype in (torch.float32, torch.float64) and tuple(T.shape) == (4, 4):
+      # one tiny kernel instead of a device-side LU (~10 launches): ms_camera_position
+      from .. import _lib
+      lib = _lib.load()
+      Tc = T.contiguous()
+      out = torch.empty(3, dtype=T.dtype, device=T.device)
+      _lib.check(lib.ms_camera_position(_lib.ptr(Tc), _lib.ptr(out), _lib.dtype_code(T.dtype),
+                                        _lib.current_stream(T.device)), 'ms_camera_position')
+      return out
+    T_world_camera = torch.inverse(T)
     return T_world_camera[0:3, 3]
 
   def transformed(self, t: torch.Tensor) -> 'CameraParams':

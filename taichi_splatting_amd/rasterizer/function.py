@@ -31,17 +31,27 @@ def _tile_rows(config: RasterConfig, image_size, tile_rows):
   return max(0, int(tile_rows[0])), min(tiles_high, int(tile_rows[1]))
 
 
-def _forward_chunk(lib, gaussians, features, ranges, o2p, image_size, cfg_c, visibility, rows, stream):
+def _strip_pixels(rows, tile_size, h):
+  """Pixel rows [y0, y1) covered by the tile rows ``rows``."""
+  return min(rows[0] * tile_size, h), min(rows[1] * tile_size, h)
+
+
+def _forward_chunk(lib, gaussians, features, ranges, o2p, image_size, cfg_c, visibility, rows, stream, crop):
   w, h = image_size
   f = features.shape[1]
   dtype = gaussians.dtype
-  image = torch.empty((h, w, f), dtype=dtype, device=gaussians.device)
-  alpha = torch.empty((h, w), dtype=dtype, device=gaussians.device)
-  if rows != (0, (h + cfg_c.tile_size - 1) // cfg_c.tile_size):
+  y0, y1 = _strip_pixels(rows, cfg_c.tile_size, h) if crop else (0, h)
+  # cropped: only the strip's pixel rows exist; the kernels address absolute rows, so they get the
+  # address row 0 WOULD have (they touch rows [y0, y1) only)
+  image = torch.empty((y1 - y0, w, f), dtype=dtype, device=gaussians.device)
+  alpha = torch.empty((y1 - y0, w), dtype=dtype, device=gaussians.device)
+  if not crop and rows != (0, (h + cfg_c.tile_size - 1) // cfg_c.tile_size):
     image.zero_(); alpha.zero_()   # rows outside the strip are not rendered
-  _lib.check(lib.ms_raster_fwd(gaussians.data_ptr(), features.data_ptr(), ranges.data_ptr(), _lib.ptr(o2p),
-                               w, h, f, cfg_c, image.data_ptr(), alpha.data_ptr(), _lib.ptr(visibility),
-                               rows[0], rows[1], _lib.dtype_code(dtype), stream), "rasterize forward")
+  if y1 > y0:
+    _lib.check(lib.ms_raster_fwd(gaussians.data_ptr(), features.data_ptr(), ranges.data_ptr(), _lib.ptr(o2p),
+                                 w, h, f, cfg_c, image.data_ptr() - y0 * w * f * image.element_size(),
+                                 alpha.data_ptr() - y0 * w * alpha.element_size(), _lib.ptr(visibility),
+                                 rows[0], rows[1], _lib.dtype_code(dtype), stream), "rasterize forward")
   return image, alpha
 
 
@@ -49,7 +59,8 @@ class _RasterFunction(torch.autograd.Function):
   """reference rasterizer/function.py:42-95"""
 
   @staticmethod
-  def forward(ctx, gaussians, features, overlap_to_point, tile_overlap_ranges, image_size, config, tile_rows):
+  def forward(ctx, gaussians, features, overlap_to_point, tile_overlap_ranges, image_size, config, tile_rows,
+              crop_to_rows=False):
     lib = _lib.load()
     _lib.require_gpu(gaussians, features, overlap_to_point, tile_overlap_ranges)
     assert gaussians.ndim == 2 and gaussians.shape[1] == 7, f"gaussians2d must be (N, 7), got {gaussians.shape}"
@@ -86,7 +97,7 @@ class _RasterFunction(torch.autograd.Function):
 
     if f <= MAX_KERNEL_FEATURES:
       image, alpha = _forward_chunk(lib, gaussians_c, features_c, ranges, o2p, (w, h), cfg_c,
-                                    visibility if config.compute_visibility else None, rows, stream)
+                                    visibility if config.compute_visibility else None, rows, stream, crop_to_rows)
     else:
       # channels are independent in the forward pass: render them MAX_KERNEL_FEATURES at a time
       images = []
@@ -94,7 +105,8 @@ class _RasterFunction(torch.autograd.Function):
         chunk = features_c[:, c0:c0 + MAX_KERNEL_FEATURES].contiguous()
         vis = visibility if (config.compute_visibility and c0 == 0) else None
         cfg_chunk = cfg_c if c0 == 0 else _lib.raster_config_c(replace(config, compute_visibility=False))
-        img, alpha_c = _forward_chunk(lib, gaussians_c, chunk, ranges, o2p, (w, h), cfg_chunk, vis, rows, stream)
+        img, alpha_c = _forward_chunk(lib, gaussians_c, chunk, ranges, o2p, (w, h), cfg_chunk, vis, rows, stream,
+                                      crop_to_rows)
         images.append(img)
         if c0 == 0:
           alpha = alpha_c
@@ -105,6 +117,7 @@ class _RasterFunction(torch.autograd.Function):
     ctx.image_size = (w, h)
     ctx.config = config
     ctx.rows = rows
+    ctx.y0 = _strip_pixels(rows, ts, h)[0] if crop_to_rows else 0
     ctx.point_heuristic = point_heuristic
     ctx.mark_non_differentiable(alpha, point_heuristic, visibility)
     ctx.save_for_backward(gaussians_c, features_c, image)
@@ -123,17 +136,20 @@ class _RasterFunction(torch.autograd.Function):
     grad_features = torch.zeros_like(features) if need_features else None
     heuristic = ctx.point_heuristic if config.compute_point_heuristic else None
     if not (need_points or need_features or heuristic is not None):
-      return None, None, None, None, None, None, None
+      return None, None, None, None, None, None, None, None
 
     grad_image = grad_image.contiguous()
+    if image.shape[0] == 0:
+      return grad_gaussians, grad_features, None, None, None, None, None, None
+    row_bytes = ctx.y0 * w * image.element_size()      # cropped strip: address of the (absent) row 0
     stream = _lib.current_stream(gaussians.device)
     dtype_code = _lib.dtype_code(gaussians.dtype)
     cfg_c = _lib.raster_config_c(config)
 
     if f <= MAX_KERNEL_FEATURES:
       _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
-                                   _lib.ptr(ctx.overlap_to_point), image.data_ptr(), grad_image.data_ptr(),
-                                   w, h, f, cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(grad_features),
+                                   _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
+                                   grad_image.data_ptr() - row_bytes * f, w, h, f, cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(grad_features),
                                    _lib.ptr(heuristic), ctx.rows[0], ctx.rows[1], dtype_code, stream),
                  "rasterize backward")
     else:
@@ -146,20 +162,20 @@ class _RasterFunction(torch.autograd.Function):
         gimg_c = grad_image[:, :, sl].contiguous()
         gfeat_c = torch.zeros_like(feat_c) if need_features else None
         _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), feat_c.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
-                                     _lib.ptr(ctx.overlap_to_point), img_c.data_ptr(), gimg_c.data_ptr(),
-                                     w, h, feat_c.shape[1], cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(gfeat_c),
+                                     _lib.ptr(ctx.overlap_to_point), img_c.data_ptr() - row_bytes * feat_c.shape[1],
+                                     gimg_c.data_ptr() - row_bytes * feat_c.shape[1], w, h, feat_c.shape[1], cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(gfeat_c),
                                      _lib.ptr(heuristic) if c0 == 0 else None, ctx.rows[0], ctx.rows[1],
                                      dtype_code, stream), "rasterize backward")
         if need_features:
           grad_features[:, sl] = gfeat_c
 
-    return grad_gaussians, grad_features, None, None, None, None, None
+    return grad_gaussians, grad_features, None, None, None, None, None, None
 
 
 def rasterize_with_tiles(gaussians2d: torch.Tensor, features: torch.Tensor,
                          overlap_to_point: torch.Tensor, tile_overlap_ranges: torch.Tensor,
                          image_size: Tuple[Integral, Integral], config: RasterConfig,
-                         tile_rows: Optional[Tuple[int, int]] = None) -> RasterOut:
+                         tile_rows: Optional[Tuple[int, int]] = None, crop_to_rows: bool = False) -> RasterOut:
   """Rasterize an image given 2d gaussians, features and tile overlap information.
 
   Parameters:
@@ -170,12 +186,13 @@ def rasterize_with_tiles(gaussians2d: torch.Tensor, features: torch.Tensor,
       image_size: (width, height)
       config: RasterConfig
       tile_rows: optional (begin, end) tile-row window (multi-GPU strips); rows outside are zero
+      crop_to_rows: with tile_rows, return only the strip's pixel rows: image (y1 - y0, W, F)
 
   Returns RasterOut(image (H, W, F), image_weight (H, W), point_heuristic (N, 2)|(0, 2),
   visibility (N,)|(0,)).  Differentiable w.r.t. gaussians2d and features.
   """
   image, image_weight, point_heuristic, visibility = _RasterFunction.apply(
-    gaussians2d, features, overlap_to_point, tile_overlap_ranges, image_size, config, tile_rows)
+    gaussians2d, features, overlap_to_point, tile_overlap_ranges, image_size, config, tile_rows, crop_to_rows)
   return RasterOut(image, image_weight, point_heuristic, visibility)
 
 

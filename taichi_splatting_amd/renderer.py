@@ -58,7 +58,8 @@ def render_gaussians(
 def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,
                      depths: torch.Tensor, camera_params: CameraParams, config: RasterConfig,
                      use_depth16: bool = False, render_median_depth: bool = False,
-                     tile_rows: Optional[Tuple[int, int]] = None) -> Rendering:
+                     tile_rows: Optional[Tuple[int, int]] = None, crop_to_rows: bool = False) -> Rendering:
+  # crop_to_rows: with tile_rows, the images hold only the strip's pixel rows (multi-GPU strips)
   # ndc depth (renderer.py:67) is computed inside the mapper's key kernel
   overlap_to_point, tile_overlap_ranges = map_to_tiles_strip(
     gaussians2d, depths.detach(), image_size=camera_params.image_size, config=config,
@@ -68,7 +69,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
   raster = rasterize_with_tiles(
     gaussians2d, features,
     tile_overlap_ranges=tile_overlap_ranges.view(-1, 2), overlap_to_point=overlap_to_point,
-    image_size=camera_params.image_size, config=config, tile_rows=tile_rows)
+    image_size=camera_params.image_size, config=config, tile_rows=tile_rows, crop_to_rows=crop_to_rows)
 
   median_depth = None
   if render_median_depth:
@@ -78,7 +79,7 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
       image_size=camera_params.image_size,
       config=replace(config, use_alpha_blending=False, saturate_threshold=config.median_threshold,
                      compute_visibility=False, compute_point_heuristic=False),
-      tile_rows=tile_rows)
+      tile_rows=tile_rows, crop_to_rows=crop_to_rows)
     median_depth = raster_depth.image.squeeze(-1)
 
   points = RenderedPoints(

@@ -47,8 +47,8 @@ def _worker(rank, world, port, ret):
     from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
     from taichi_splatting_amd.testing import random_2d_gaussians
     torch.manual_seed(0)     # replicated scene
-    size = (160, 112)
-    g = random_2d_gaussians(1500, size, scale_factor=1.5)
+    size = (128, 96)
+    g = random_2d_gaussians(700, size, scale_factor=1.5)
     p, f = project_gaussians2d(g).double(), g.feature.double()
     cfg = orast.Cfg()
     tiles_high = (size[1] + 15) // 16
@@ -80,3 +80,85 @@ def test_two_rank_strip_backward_allreduce():
   ret = mgr.dict()
   mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
   assert dict(ret) == {0: True, 1: True}
+
+
+# ---- gaussian-sharded + strip-sharded path: routing and the all-to-all exchange (gloo) -----------
+
+def test_routing_plan_matches_brute_force():
+  from taichi_splatting_amd.distributed import route_to_strips, expand_routes
+  torch.manual_seed(3)
+  tiles_high, n = 13, 500
+  lo = torch.randint(0, tiles_high, (n,))
+  hi = torch.minimum(lo + torch.randint(0, 6, (n,)), torch.tensor(tiles_high))     # some empty (hi == lo)
+  for bounds in ([0, 13], [0, 6, 13], [0, 4, 4, 9, 13], [0, 1, 2, 3, 13]):
+    world = len(bounds) - 1
+    first, copies, counts = route_to_strips(lo, hi, bounds)
+    send_index, dest = expand_routes(first, copies, int(counts.sum()))
+    want = [(d, i) for d in range(world) for i in range(n)
+            if hi[i] > lo[i] and lo[i] < bounds[d + 1] and hi[i] > bounds[d]
+            # empty strips in the middle of a span still receive the splat (harmless): count them too
+            or (hi[i] > lo[i] and bounds[d] == bounds[d + 1] and lo[i] < bounds[d] < hi[i])]
+    got = list(zip(dest.tolist(), send_index.tolist()))
+    # every (strip, splat) intersection is routed, in (dest, index) order, and nothing is routed twice
+    assert set(w for w in want if bounds[w[0]] != bounds[w[0] + 1]) <= set(got)
+    assert got == sorted(set(got))
+    assert counts.tolist() == [sum(1 for d, _ in got if d == r) for r in range(world)]
+
+
+def _sharded_worker(rank, world, port, ret):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from oracle import mapper as omap, raster as orast
+    from taichi_splatting_amd import RasterConfig
+    from taichi_splatting_amd.distributed import shard_range, strip_bounds, exchange_to_strips
+    from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+    from taichi_splatting_amd.testing import random_2d_gaussians
+    torch.manual_seed(0)     # every rank builds the same scene and keeps its shard
+    size = (96, 80)
+    g = random_2d_gaussians(400, size, scale_factor=1.5)
+    g.depths[::7] = g.depths[0]                   # depth ties: order must fall back to the gaussian index
+    p_full, f_full, d_full = project_gaussians2d(g), g.feature.clone(), g.depths.squeeze(-1) if g.depths.dim() > 1 else g.depths
+    cfg, rcfg = orast.Cfg(), RasterConfig()
+    tiles_high = (size[1] + 15) // 16
+    bounds = strip_bounds(tiles_high, world)
+    rows = (bounds[rank], bounds[rank + 1])
+
+    b, e = shard_range(p_full.shape[0], world, rank)
+    p = p_full[b:e].clone().requires_grad_(True)
+    f = f_full[b:e].clone().requires_grad_(True)
+    gid = torch.arange(b, e)
+    g2, f2, d2, gid2 = exchange_to_strips(p, f, d_full[b:e], size, rcfg, bounds, global_index=gid)
+    # received splats: by source rank, in source order = ascending global index
+    assert torch.equal(gid2, torch.sort(gid2).values)
+    assert torch.equal(g2.detach(), p_full[gid2]) and torch.equal(d2, d_full[gid2])
+
+    o2p, ranges, _ = omap.map_to_tiles(g2.detach().numpy(), d2.numpy(), size, 16, tile_rows=rows)
+    o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+    img, _, _ = orast.forward(g2.detach().double(), f2.detach().double(), ranges, o2p, size, cfg, tile_rows=rows)
+    G = torch.ones_like(img)
+    gp, gf, _ = orast.backward(g2.detach().double(), f2.detach().double(), ranges, o2p, img, G, size, cfg, tile_rows=rows)
+    torch.autograd.backward([g2, f2], [gp.float(), gf.float()])     # reverse all-to-all + scatter-add
+
+    o2p_f, ranges_f, _ = omap.map_to_tiles(p_full.numpy(), d_full.numpy(), size, 16)
+    o2p_f, ranges_f = torch.from_numpy(o2p_f), torch.from_numpy(ranges_f)
+    img_f, _, _ = orast.forward(p_full.double(), f_full.double(), ranges_f, o2p_f, size, cfg)
+    gp_f, gf_f, _ = orast.backward(p_full.double(), f_full.double(), ranges_f, o2p_f, img_f, torch.ones_like(img_f), size, cfg)
+    r0, r1 = rows[0] * 16, min(rows[1] * 16, size[1])
+    ok = (torch.allclose(img[r0:r1], img_f[r0:r1], atol=1e-12)
+          and torch.allclose(p.grad.double(), gp_f[b:e], rtol=1e-5, atol=1e-5 * float(gp_f.abs().max()))
+          and torch.allclose(f.grad.double(), gf_f[b:e], rtol=1e-5, atol=1e-6)
+          and float(gp_f[b:e].abs().sum()) > 0)
+    ret[rank] = bool(ok)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_exchange_matches_full_frame(world):
+  port = _free_port()
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_sharded_worker, args=(world, port, ret), nprocs=world, join=True)
+  assert dict(ret) == {r: True for r in range(world)}

@@ -114,3 +114,26 @@ def test_sh_random_f32_vs_oracle(seed):
   assert torch.allclose(h_out[0].cpu(), o_out[0], atol=1e-5)
   for g_h, g_o in zip(h_grad, o_grad):
     assert torch.allclose(g_h.cpu(), g_o, atol=1e-5), (g_h.cpu() - g_o).abs().max()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_camera_position_kernel_matches_torch_inverse(dtype):
+  # perspective/params.py:62-65: inverse(T_camera_world)[0:3, 3]
+  from taichi_splatting_amd.testing import random_camera
+  for seed in range(5):
+    torch.manual_seed(seed)
+    cam = random_camera(image_size=(64, 48)).to(device='cuda:0', dtype=dtype)
+    want = torch.inverse(cam.T_camera_world.cpu().double())[0:3, 3]
+    got = cam.camera_position
+    assert got.dtype == dtype and got.is_cuda
+    assert torch.allclose(got.cpu().double(), want, rtol=1e-5 if dtype == torch.float32 else 1e-12, atol=1e-6 if dtype == torch.float32 else 1e-12)
+  # general (non-rigid) matrix and the autograd fallback
+  T = torch.randn(4, 4, dtype=dtype, device='cuda:0') + 3 * torch.eye(4, dtype=dtype, device='cuda:0')
+  cam2 = cam.__class__(projection=cam.projection, T_camera_world=T, near_plane=cam.near_plane, far_plane=cam.far_plane,
+                       image_size=cam.image_size)
+  assert torch.allclose(cam2.camera_position.cpu().double(), torch.inverse(T.cpu().double())[0:3, 3], rtol=1e-4, atol=1e-5)
+  Tg = T.clone().requires_grad_(True)
+  cam3 = cam.__class__(projection=cam.projection, T_camera_world=Tg, near_plane=cam.near_plane, far_plane=cam.far_plane,
+                       image_size=cam.image_size)
+  cam3.camera_position.sum().backward()
+  assert Tg.grad is not None

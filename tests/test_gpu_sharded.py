@@ -1,0 +1,130 @@
+"""-m gpu: the gaussian-sharded / strip-sharded renderer (distributed.render_sharded_step) with REAL
+processes: ``world`` ranks share the one GPU of the box, process group = gloo, the all-to-all staged
+through host memory (all_to_all_via_host).  Every rank holds only its shard of the gaussians; its strip
+and the gradients of its shard must equal the single-process full-frame render."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def _worker(rank, world, port, dtype_name, balance, ret):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from taichi_splatting_amd import RasterConfig, render_gaussians
+    from taichi_splatting_amd.distributed import (render_sharded_step, shard_range, strip_bounds,
+                                                  all_to_all_via_host)
+    from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(world)           # same scene on every rank; each keeps its shard
+    size = (320, 208)
+    cam = random_camera(image_size=size)
+    n = 20000
+    g = random_3d_gaussians(n, cam, scale_factor=1.5, alpha_range=(0.1, 0.9))
+    g = g.replace(feature=(torch.rand(n, 3, 16) - 0.5) * 0.5).to(dtype=dtype)
+    cam = cam.to(device=DEV, dtype=dtype)
+    cfg = RasterConfig()
+    torch.manual_seed(0)
+    G = torch.randn(size[1], size[0], 3, dtype=dtype, device=DEV)
+
+    tiles_high = (size[1] + 15) // 16
+    bounds = strip_bounds(tiles_high, world, [1.0 + (r % 3) for r in range(tiles_high)] if balance else None)
+    b, e = shard_range(n, world, rank)
+    shard = g[b:e].to(DEV).requires_grad_(True)
+    rendering, _ = render_sharded_step(shard, cam, cfg, lambda img, px: (img * G[px[0]:px[1]]).sum(), use_sh=True,
+                                       rank=rank, world_size=world, index_offset=b, bounds=bounds,
+                                       exchange=all_to_all_via_host)
+
+    full = g.to(DEV).requires_grad_(True)
+    r = render_gaussians(full, cam, cfg, use_sh=True)
+    (r.image * G).sum().backward()
+
+    y0, y1 = bounds[rank] * 16, min(bounds[rank + 1] * 16, size[1])
+    tol = 1e-10 if dtype == torch.float64 else 1e-5
+    ok = rendering.image.shape[0] == y1 - y0 and torch.allclose(rendering.image, r.image[y0:y1], atol=tol)
+    ok = ok and torch.allclose(rendering.image_weight, r.image_weight[y0:y1], atol=tol)
+    ids = rendering.points.idx
+    ok = ok and bool((ids[1:] > ids[:-1]).all()) and int(ids.min()) >= 0 and int(ids.max()) < n
+    worst = 0.0
+    for got, want in zip([shard.position.grad, shard.log_scaling.grad, shard.rotation.grad, shard.alpha_logit.grad, shard.feature.grad],
+                         [full.position.grad, full.log_scaling.grad, full.rotation.grad, full.alpha_logit.grad, full.feature.grad]):
+      want = want[b:e]
+      scale = max(1.0, want.abs().max().item())
+      err = ((got - want).abs().max() / scale).item()
+      worst = max(worst, err)
+      ok = ok and err < (1e-8 if dtype == torch.float64 else 2e-3)
+    ret[rank] = (bool(ok), worst)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,bounds', [(1, [0, 13]), (2, [0, 6, 13]), (5, [0, 4, 4, 9, 12, 13]), (8, None), (64, None)])
+def test_routing_kernels_match_torch_formulation(world, bounds):
+  # csrc/strip_route.hip against the torch formulation of the same split: identical send buffer
+  # (bit-exact rows, order, split sizes) and identical gradient return path
+  from taichi_splatting_amd import RasterConfig
+  from taichi_splatting_amd import distributed as D
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  torch.manual_seed(world)
+  size = (300, 13 * 16 - 5) if bounds is not None else (256, 1024)
+  n = 50000
+  g = random_2d_gaussians(n, size, scale_factor=2.0, alpha_range=(0.0, 0.9)).to(DEV)      # some alphas below the threshold
+  p = project_gaussians2d(g)
+  p[::97, 1] = float('nan'); p[5::101, 4] = float('inf'); p[7::89, 1] = -500.0; p[11::83, 1] = 1e6
+  cfg = RasterConfig()
+  tiles_high = (size[1] + 15) // 16
+  if bounds is None:
+    bounds = D.strip_bounds(tiles_high, world)
+  ids = torch.randperm(n, device=DEV)
+
+  def loopback(send, send_counts, recv_counts, group):
+    return send.clone()
+
+  out = {}
+  for force in (False, True):
+    D.FORCE_TORCH_ROUTING = force
+    try:
+      pp = p.clone().requires_grad_(True); ff = g.feature.clone().requires_grad_(True)
+      g2, f2, d, gid = D.exchange_to_strips(pp, ff, g.depths, size, cfg, bounds, global_index=ids, index_offset=1000,
+                                            exchange=loopback)
+      torch.manual_seed(1)
+      (g2 * torch.randn_like(g2)).sum().backward(retain_graph=True)
+      (f2 * torch.randn_like(f2)).sum().backward()
+      out[force] = (g2.detach(), f2.detach(), d, gid, pp.grad, ff.grad)
+    finally:
+      D.FORCE_TORCH_ROUTING = False
+  assert out[False][0].shape[0] > n // 2
+  for k, (a, b) in enumerate(zip(out[False], out[True])):
+    a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+    assert a.shape == b.shape
+    if k < 4:
+      assert torch.equal(a, b), k
+    else:      # sums over the copies of a splat: atomics, order not fixed
+      assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), k
+
+
+@pytest.mark.parametrize('world,dtype_name,balance', [(2, 'float64', False), (3, 'float64', True), (4, 'float32', False),
+                                                      (3, 'float32', True)])
+def test_sharded_step_matches_full_frame(world, dtype_name, balance):
+  port = _free_port()
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_worker, args=(world, port, dtype_name, balance, ret), nprocs=world, join=True)
+  assert all(v[0] for v in dict(ret).values()) and len(ret) == world, dict(ret)

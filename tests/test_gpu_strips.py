@@ -49,3 +49,32 @@ def test_strips_compose_to_full_frame(world, dtype):
     scale = max(1.0, want.abs().max().item())
     assert torch.allclose(got, want, atol=(1e-8 if dtype == torch.float64 else 2e-3) * scale), \
       ((got - want).abs().max(), scale)
+
+
+@pytest.mark.parametrize('features', [3, 6])
+def test_cropped_strip_equals_rows_of_full_frame(features):
+  # rasterize_with_tiles(..., tile_rows, crop_to_rows=True): only the strip's pixel rows are allocated
+  from taichi_splatting_amd import rasterize_with_tiles, map_to_tiles
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  torch.manual_seed(features)
+  size = (200, 150)            # 10 tile rows, the last one partial
+  cfg = RasterConfig()
+  g = random_2d_gaussians(5000, size, num_channels=features, scale_factor=1.5).to(DEV)
+  p = project_gaussians2d(g)
+  o2p, ranges = map_to_tiles(p, g.depths, size, cfg)
+  G = torch.randn(size[1], size[0], features, device=DEV)
+  pf = p.clone().requires_grad_(True); ff = g.feature.clone().requires_grad_(True)
+  full = rasterize_with_tiles(pf, ff, o2p, ranges.view(-1, 2), size, cfg)
+  gp_sum, gf_sum = torch.zeros_like(p), torch.zeros_like(g.feature)
+  for rows in ((0, 3), (3, 3), (3, 9), (9, 10)):
+    ps = p.clone().requires_grad_(True); fs = g.feature.clone().requires_grad_(True)
+    y0, y1 = rows[0] * 16, min(rows[1] * 16, size[1])
+    out = rasterize_with_tiles(ps, fs, o2p, ranges.view(-1, 2), size, cfg, tile_rows=rows, crop_to_rows=True)
+    assert out.image.shape == (y1 - y0, size[0], features) and out.image_weight.shape == (y1 - y0, size[0])
+    assert torch.equal(out.image, full.image[y0:y1]) and torch.equal(out.image_weight, full.image_weight[y0:y1])
+    (out.image * G[y0:y1]).sum().backward()
+    gp_sum += ps.grad; gf_sum += fs.grad
+  (full.image * G).sum().backward()
+  assert torch.allclose(gp_sum, pf.grad, rtol=1e-4, atol=1e-4 * pf.grad.abs().max().item())
+  assert torch.allclose(gf_sum, ff.grad, rtol=1e-4, atol=1e-5)
