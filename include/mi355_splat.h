@@ -197,6 +197,14 @@ int ms_fractional_step(int kind, int vector, float* lr_step, const int64_t* inde
                        const float* grad, int64_t m_count, int d, float lr, float beta1,
                        float beta2, float eps, int bias_correction, void* stream);
 
+/* ---- Morton codes --------------------------------------------------------------------
+ * out_codes[i] = 63-bit Z-order code of points3[i] (N, 3 float32) on the grid of cell size inc3_host anchored at
+ * lower3_host (3 floats each, host memory) with `size` cells per axis (<= 2^21): cell = clamp((p - lower) / inc,
+ * 0, size - 1) truncated; x, y, z bits interleaved from bit 0 (misc/morton_sort.py:25-33,56-70,94-99).
+ * Sort with ms_radix_sort_pairs (key_bytes 8) for misc/morton_sort.py:113-119 argsort. */
+int ms_morton_codes64(const float* points3, int64_t n, const float* lower3_host, const float* inc3_host,
+                      uint32_t size, uint64_t* out_codes, void* stream);
+
 /* ---- camera position ----------------------------------------------------------------------------------
  * out_position3 = inverse(T_camera_world)[0:3, 3] for a row-major 4x4 (perspective/params.py:62-65), one
  * launch instead of a device-side LU. */

@@ -16,6 +16,9 @@ Parity status (see DESIGN.md "Oracle"):
     tests/test_rasterizer.py:62-90), autograd-vs-literal-backward agreement, the visibility identity
     (tests/test_visibility.py:34-64) and brute-force mapper invariants.
 
+  * Morton codes (N4): reference kernels need the Taichi runtime (absent) — pinned by known answers of the
+    published bit interleave and an independent bitwise formulation ("parity unpinned" by reference data).
+
 Each function cites the reference file:line (relative to /root/reference/taichi_splatting) it follows.
 """
-from . import projection, sh, mapper, raster, render, optim  # noqa: F401
+from . import projection, sh, mapper, raster, render, optim, morton  # noqa: F401

@@ -39,7 +39,7 @@ def install_as_taichi_splatting():
   for sub in ('data_types', 'renderer', 'rendering', 'taichi_queue', 'spherical_harmonics',
               'indexed_spherical_harmonics', 'perspective', 'perspective.params',
               'perspective.projection', 'mapper', 'mapper.tile_mapper', 'rasterizer',
-              'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'optim', 'optim.fractional',
+              'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'misc.morton_sort', 'optim', 'optim.fractional',
               'optim.visibility_aware', 'optim.parameter_class', 'optim.autograd', 'optim.util'):
     mod = importlib.import_module(f'{__name__}.{sub}')
     sys.modules.setdefault(f'taichi_splatting.{sub}', mod)

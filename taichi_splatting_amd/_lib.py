@@ -56,6 +56,7 @@ SIGNATURES = {
   'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
   'ms_find_ranges': (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
   'ms_fractional_step': (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+  'ms_morton_codes64': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
   'ms_camera_position': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
   'ms_strip_route_blocks': (c_int, [c_int]),
   'ms_strip_route_count': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

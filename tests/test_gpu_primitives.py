@@ -1,4 +1,5 @@
 """-m gpu: scan / radix sort / ranges against torch (bit-exact integer work)."""
+import numpy as np
 import pytest
 import torch
 
@@ -65,3 +66,32 @@ def test_segmented_sort_pairs():
     wk, order = torch.sort(k[s:e], stable=True)
     assert torch.equal(ko[s:e], wk)
     assert torch.equal(vo[s:e].long(), order + s)
+
+
+@pytest.mark.parametrize('n,resolution', [(1, 0.01), (1000, 0.001), (300000, 0.01), (50000, 2.0)])
+def test_morton_codes_and_argsort_match_oracle(n, resolution):
+  # ms_morton_codes64 + 64-bit radix argsort against oracle/morton.py (bit-exact codes, identical stable order)
+  from oracle import morton as omorton
+  from taichi_splatting_amd.misc import morton_sort
+  torch.manual_seed(n)
+  pts = (torch.rand(n, 3) * torch.tensor([8.0, 3.0, 20.0]) - 2.0)
+  if n > 10:
+    pts[3] = pts[7]                                   # duplicates: stable order decides
+  dev = pts.cuda()
+  codes = morton_sort.morton_codes(dev, resolution).cpu().numpy().astype(np.uint64)
+  want = omorton.morton_codes(pts.numpy(), resolution)
+  assert codes.shape == (n,) and np.array_equal(codes, want)
+  order = morton_sort.argsort(dev, resolution).cpu().numpy()
+  assert np.array_equal(order, omorton.argsort(pts.numpy(), resolution))
+  keep = morton_sort.argsort_dedup(dev, resolution).cpu().numpy()
+  assert np.array_equal(keep, omorton.argsort_dedup(pts.numpy(), resolution))
+  assert torch.equal(morton_sort.sort(dev, resolution).cpu(), pts[torch.from_numpy(order).long()])
+  assert torch.equal(morton_sort.sort_dedup(dev, resolution).cpu(), pts[torch.from_numpy(keep).long()])
+
+
+def test_morton_nan_and_empty():
+  from taichi_splatting_amd.misc import morton_sort
+  assert morton_sort.argsort(torch.empty(0, 3, device='cuda:0'), 0.1).shape == (0,)
+  pts = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, float('inf'), 0.5]], device='cuda:0')
+  codes = morton_sort.morton_codes(pts, 0.25)
+  assert codes.shape == (3,) and int(codes[0]) == 0 and int(codes[1]) == 0b111000000   # cell (4, 4, 4)
