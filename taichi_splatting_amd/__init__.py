@@ -40,7 +40,14 @@ def install_as_taichi_splatting():
               'indexed_spherical_harmonics', 'perspective', 'perspective.params',
               'perspective.projection', 'mapper', 'mapper.tile_mapper', 'rasterizer',
               'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'misc.morton_sort', 'optim', 'optim.fractional',
-              'optim.visibility_aware', 'optim.parameter_class', 'optim.autograd', 'optim.util'):
+              'optim.visibility_aware', 'optim.parameter_class', 'optim.autograd', 'optim.util',
+              'benchmarks', 'benchmarks.util', 'benchmarks.bench_projection', 'benchmarks.bench_sh',
+              'benchmarks.bench_tilemapper', 'benchmarks.bench_rasterizer', 'examples',
+              'examples.fit_image_gaussians'):
     mod = importlib.import_module(f'{__name__}.{sub}')
     sys.modules.setdefault(f'taichi_splatting.{sub}', mod)
+  # the reference keeps its scene generators under tests/ (tests/random_data.py)
+  testing = importlib.import_module(f'{__name__}.testing')
+  sys.modules.setdefault('taichi_splatting.tests', testing)
+  sys.modules.setdefault('taichi_splatting.tests.random_data', importlib.import_module(f'{__name__}.testing.random_data'))
   return me

@@ -85,4 +85,24 @@ __device__ __forceinline__ void atomic_add_noret(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sum NV per-thread values over a 256-thread block and add the block totals to dst[0..NV) with ONE atomic per
+// value per block (wave DPP reduce -> LDS -> first NV threads).  For whole-launch sums (camera gradients):
+// combined with a grid-stride loop over a bounded number of blocks this keeps the same-address atomic count
+// in the thousands instead of one per wave.
+template <typename T, int NV>
+__device__ __forceinline__ void block_sum_commit(const T (&v)[NV], T* __restrict__ dst, T* lds /* >= 4 * NV */) {
+  const int lane = lane_id(), wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const T s = wave_sum_to_lane63(v[k]);
+    if (lane == 63) lds[wave * NV + k] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NV) {
+    T t = T(0);
+    for (int w = 0; w < waves; ++w) t += lds[w * NV + threadIdx.x];
+    if (t != T(0)) atomic_add_noret(dst + threadIdx.x, t);
+  }
+}
+
 }  // namespace ms

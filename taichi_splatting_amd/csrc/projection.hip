@@ -76,13 +76,14 @@ project_bwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
                    T* __restrict__ d_position, T* __restrict__ d_log_scaling,
                    T* __restrict__ d_rotation, T* __restrict__ d_alpha_logit,
                    T* __restrict__ d_camera) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-
   T cam_grad[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) cam_grad[k] = T(0);
+  __shared__ T s_cam[4 * 16];
 
-  if (i < v) {
+  // grid-stride: with camera gradients the launch is capped at a few thousand blocks so that the 16
+  // whole-launch sums cost one atomic per value per BLOCK
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < v; i += (int64_t)gridDim.x * blockDim.x) {
     Camera<T> cam;
     load_camera(Tcw, proj, cam);
     const int64_t idx = indexes[i];
@@ -109,14 +110,7 @@ project_bwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
     d_alpha_logit[idx] = dal;
   }
 
-  if (d_camera) {
-    // camera gradient = sum over points: wave reduce, then 16 atomics per wave
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const T s = wave_sum_to_lane63(cam_grad[k]);
-      if (lane_id() == 63 && s != T(0)) atomic_add_noret(d_camera + k, s);
-    }
-  }
+  if (d_camera) block_sum_commit<T, 16>(cam_grad, d_camera, s_cam);
 }
 
 }  // namespace ms
@@ -201,7 +195,9 @@ extern "C" int ms_project_bwd(const void* position, const void* log_scaling, con
                "null input");
   MS_CHECK_ARG(grad_points7 && grad_depth, "null incoming gradient");
   MS_CHECK_ARG(grad_position && grad_log_scaling && grad_rotation && grad_alpha_logit, "null output");
-  const dim3 block(256), grid((unsigned)div_up(v, 256));
+  int64_t blocks = div_up(v, 256);
+  if (grad_camera && blocks > 2048) blocks = 2048;       // bounded atomic count for the camera sums
+  const dim3 block(256), grid((unsigned)blocks);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MS_F32)
     project_bwd_kernel<float><<<grid, block, 0, s>>>(

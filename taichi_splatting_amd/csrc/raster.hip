@@ -455,8 +455,8 @@ using namespace ms;
 
 // product-path kernels (float, F = 3, plain pdf, blending): raster_fast.hip
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
-                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
-                        int num_tiles, hipStream_t s);
+                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
+                        int row_begin, int num_tiles, hipStream_t s);
 bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
@@ -521,13 +521,13 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
   const int tiles_wide = (image_w + cfg->tile_size - 1) / cfg->tile_size;
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending &&
-      !(cfg->compute_visibility && out_visibility)) {
-    const bool ok = use_subpatch_kernels()
+  if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending) {
+    void* vis = (cfg->compute_visibility && out_visibility) ? out_visibility : nullptr;
+    const bool ok = (use_subpatch_kernels() && !vis)
         ? ms_raster_fwd_sub(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
                             out_alpha, tile_row_begin, num_tiles, s)
         : ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                             out_alpha, tile_row_begin, num_tiles, s);
+                             out_alpha, vis, tile_row_begin, num_tiles, s);
     if (ok) {
       MS_CHECK_LAUNCH();
       return 0;

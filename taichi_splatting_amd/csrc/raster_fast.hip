@@ -34,15 +34,22 @@ namespace ms {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int TS>
+// VIS: also accumulate each splat's visibility = the sum of its blend weights over all pixels
+// (forward.py:126-131): one 6-step DPP sum per (patch, splat) hit with a contribution, summed over the
+// tile's patches in LDS (single-lane ds_add_f32) and committed with ONE global atomic per (tile, splat) —
+// the pass is bound by the global atomic rate, so the count is what matters.
+template <int TS, bool VIS>
 __global__ void __launch_bounds__(TS * TS)
 raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                         const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
-                        FastParams rp, float* __restrict__ image, float* __restrict__ image_alpha) {
+                        FastParams rp, float* __restrict__ image, float* __restrict__ image_alpha,
+                        float* __restrict__ visibility) {
   using G = TileGeom<TS>;
   constexpr int BATCH = G::BATCH;
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ float4 s_cull[BATCH * 2];
+  __shared__ int32_t s_id[VIS ? BATCH : 1];
+  __shared__ float s_vis[VIS ? BATCH : 1];
 
   const int tile_id = rp.tile_begin + blockIdx.x;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
@@ -71,7 +78,14 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   for (int begin = start; begin < end; begin += BATCH) {
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     __syncthreads();                       // previous batch fully consumed
-    if (stager && begin + t < end) write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
+    if (VIS && stager) {
+      if (begin > start && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);   // previous batch
+      s_vis[t] = 0.0f;
+    }
+    if (stager && begin + t < end) {
+      write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
+      if (VIS) s_id[t] = raw.id;
+    }
     if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
     if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
     __syncthreads();
@@ -112,6 +126,12 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
         T -= w;
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
+        if (VIS) {
+          if (__ballot(w != 0.0f)) {
+            const float total = wave_sum_to_lane63(w);
+            if (lane == 63) atomicAdd(&s_vis[r + b], total);
+          }
+        }
 
 #if !MS_LEAN_FWD
         if (!more) break;
@@ -121,6 +141,11 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 #endif
       }
     }
+  }
+
+  if (VIS && end > start) {                // last batch
+    __syncthreads();
+    if (stager && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);
   }
 
   if (in_bounds) {
@@ -312,12 +337,17 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
 
 // Called from raster.hip's dispatch.  Returns true if the fast path handled the launch.
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
-                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
-                        int num_tiles, hipStream_t s) {
+                        int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
+                        int row_begin, int num_tiles, hipStream_t s) {
   const FastParams rp = make_fast_params(w, h, cfg, row_begin);
   const dim3 grid((unsigned)num_tiles);
-#define MS_GO(TS) raster_fwd_f32x3_kernel<TS><<<grid, dim3(TS * TS), 0, s>>>(                               \
-      (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha)
+#define MS_GO(TS)                                                                                               \
+  do {                                                                                                          \
+    if (visibility) raster_fwd_f32x3_kernel<TS, true><<<grid, dim3(TS * TS), 0, s>>>(                           \
+        (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, (float*)visibility); \
+    else raster_fwd_f32x3_kernel<TS, false><<<grid, dim3(TS * TS), 0, s>>>(                                     \
+        (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, nullptr);     \
+  } while (0)
   switch (cfg->tile_size) {
     case 8: MS_GO(8); return true;
     case 16: MS_GO(16); return true;

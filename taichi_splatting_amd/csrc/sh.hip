@@ -41,10 +41,10 @@ sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
               const T* __restrict__ g_out, T* __restrict__ g_params, T* __restrict__ g_positions,
               T* __restrict__ g_cam) {
   constexpr int D = (DEG + 1) * (DEG + 1);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-
   T dcam[3] = {T(0), T(0), T(0)};
-  if (i < v) {
+  __shared__ T s_cam[4 * 3];
+  // grid-stride (the launch is capped when the camera gradient is wanted: one atomic per value per block)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < v; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t idx = indexes[i];
     const T dx = positions[idx * 3 + 0] - cam_pos[0];
     const T dy = positions[idx * 3 + 1] - cam_pos[1];
@@ -86,16 +86,10 @@ sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
         atomic_add_noret(g_positions + idx * 3 + 1, gy);
         atomic_add_noret(g_positions + idx * 3 + 2, gz);
       }
-      dcam[0] = -gx; dcam[1] = -gy; dcam[2] = -gz;
+      dcam[0] -= gx; dcam[1] -= gy; dcam[2] -= gz;
     }
   }
-  if (g_cam) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const T s = wave_sum_to_lane63(dcam[k]);
-      if (lane_id() == 63 && s != T(0)) atomic_add_noret(g_cam + k, s);
-    }
-  }
+  if (g_cam) block_sum_commit<T, 3>(dcam, g_cam, s_cam);
 }
 
 
@@ -172,7 +166,8 @@ static int launch_sh_bwd(const void* params, const void* positions, const int64_
                          const void* cam, int64_t v, int f, int degree, const void* out, const void* g_out,
                          void* g_params, void* g_positions, void* g_cam, int unique, hipStream_t s) {
   const dim3 block(256), grid((unsigned)div_up(v, 256));
-  if (out && g_params && !g_positions && !g_cam && f <= SH_MAX_F) {
+  const bool fast_params = out && g_params && f <= SH_MAX_F;
+  if (fast_params) {
 #define MS_SH_BWD_P(DEG)                                                                                  \
   do {                                                                                                    \
     if (unique) sh_bwd_params_kernel<T, DEG, true><<<grid, block, 0, s>>>((const T*)positions, indexes,   \
@@ -187,10 +182,12 @@ static int launch_sh_bwd(const void* params, const void* positions, const int64_
       default: MS_SH_BWD_P(3); break;
     }
 #undef MS_SH_BWD_P
-    return 0;
+    if (!g_positions && !g_cam) return 0;
+    g_params = nullptr;        // the direction gradients below: a second, atomics-free-for-params pass
   }
+  const dim3 grid_dir((unsigned)(g_cam ? (div_up(v, 256) < 2048 ? div_up(v, 256) : 2048) : div_up(v, 256)));
 #define MS_SH_BWD(DEG)                                                                              \
-  sh_bwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, indexes,      \
+  sh_bwd_kernel<T, DEG><<<grid_dir, block, 0, s>>>((const T*)params, (const T*)positions, indexes,      \
                                                 (const T*)cam, v, f, (const T*)g_out, (T*)g_params, \
                                                 (T*)g_positions, (T*)g_cam)
   switch (degree) {

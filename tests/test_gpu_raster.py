@@ -203,7 +203,7 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
   # (itself checked against the oracle above), incl. many LDS batches per tile, image sizes that are
   # not tile multiples, point heuristics
   torch.manual_seed(n + tile_size)
-  cfg = cfg_for(tile_size, compute_point_heuristic=True)
+  cfg = cfg_for(tile_size, compute_point_heuristic=True, compute_visibility=True)
   g = random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha).to(DEV)
   p32 = project_gaussians2d(g)
   o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
@@ -217,14 +217,15 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
     out = rasterize_with_tiles(p, f, o2p, ranges, size, cfg)
     (out.image * G.to(dtype)).sum().backward()
     res[dtype] = (out.image.detach().double(), out.image_weight.detach().double(), p.grad.double(), f.grad.double(),
-                  out.point_heuristic.double())
-  img64, a64, gp64, gf64, h64 = res[torch.float64]
-  img32, a32, gp32, gf32, h32 = res[torch.float32]
+                  out.point_heuristic.double(), out.visibility.double())
+  img64, a64, gp64, gf64, h64, v64 = res[torch.float64]
+  img32, a32, gp32, gf32, h32, v32 = res[torch.float32]
   err = (img32 - img64).abs().max(-1).values
   # a contribution gate (alpha > 1/255) flipping in f32 moves a pixel by ~alpha_threshold * |f|
   assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2, (err.quantile(0.9999), err.max())
   assert (a32 - a64).abs().quantile(0.9999) < 1e-4
-  for got, want in ((gp32, gp64), (gf32, gf64), (h32, h64)):
+  assert v64.sum() > 0
+  for got, want in ((gp32, gp64), (gf32, gf64), (h32, h64), (v32, v64)):
     scale_ = want.abs().max().item() + 1e-12
     rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
     assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
