@@ -57,7 +57,7 @@ __device__ __forceinline__ double fast_rcp(double x) { return 1.0 / x; }
 template <typename T, int F, int BATCH>
 __device__ __forceinline__ void stage_batch(const T* __restrict__ points, const T* __restrict__ feats,
                                             const int32_t* __restrict__ o2p, int begin, int count,
-                                            T alpha_threshold, bool cull, Splat<T, F>* s_splat,
+                                            T alpha_threshold, bool antialias, Splat<T, F>* s_splat,
                                             CullBox<T>* s_cull, int32_t* s_id) {
   for (int t = threadIdx.x; t < count; t += blockDim.x) {
     const int32_t id = o2p[begin + t];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void stage_batch(const T* __restrict__ points, const 
 
     CullBox<T> b;
     b.cx = s.mx; b.cy = s.my;
-    if (cull) {
+    if (!antialias) {
       // half extents of the bounding box of the ellipse  alpha * g == threshold; NaN (alpha below
       // the threshold) fails every comparison below and culls the splat, which cannot contribute
       const T gs = t_sqrt(2 * t_log(s.alpha / alpha_threshold));
@@ -84,7 +84,28 @@ __device__ __forceinline__ void stage_batch(const T* __restrict__ points, const 
       b.ex = t_sqrt(v1x * v1x + v2x * v2x) * T(1.001) + T(0.01);
       b.ey = t_sqrt(v1y * v1y + v2y * v2y) * T(1.001) + T(0.01);
     } else {
-      b.ex = T(1e30); b.ey = T(1e30);
+      // antialiased pdf (generic.py:341-357): p = 2 pi ix iy, ix = sx (S((tx + .5)/sx) - S((tx - .5)/sx)),
+      // S(z) = 1 / (1 + exp(-h(z))), h = 1.6 z + 0.07 z^3.  For |tx| >= .5: ix <= sx (1 - S(z)) <= sx exp(-h(z))
+      // with z = (|tx| - .5) / sx, and iy <= sy.  So alpha p > threshold needs exp(-h(zx)) > q / (sx sy),
+      // q = threshold / (2 pi alpha), i.e. h(zx) < L = ln(sx sy / q): |tx| < .5 + sx zx*, likewise |ty|; the
+      // contribution region lies inside that oriented rectangle.  h is convex and increasing for z >= 0, so
+      // Newton from z0 = L / 1.6 >= root descends monotonically and every iterate bounds the root from above.
+      const T q = alpha_threshold / (T(6.283185307179586) * s.alpha);
+      const T L = t_log(s.sx * s.sy / q);
+      if (!(L > T(0))) {
+        b.ex = T(-1e30); b.ey = T(-1e30);      // alpha * p <= threshold everywhere (also NaN / alpha <= 0)
+      } else {
+        T z = L / T(1.6);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const T h = T(1.6) * z + T(0.07) * z * z * z;
+          z -= (h - L) / (T(1.6) + T(0.21) * z * z);
+        }
+        z = z * T(1.001) + T(0.001);
+        const T rx = T(0.5) + s.sx * z, ry = T(0.5) + s.sy * z;
+        b.ex = t_abs(s.ax) * rx + t_abs(s.ay) * ry + T(0.01);
+        b.ey = t_abs(s.ay) * rx + t_abs(s.ax) * ry + T(0.01);
+      }
     }
     s_cull[t] = b;
   }
@@ -97,11 +118,71 @@ __device__ __forceinline__ bool patch_hit(const CullBox<T>& b, T x0, T y0) {
          (b.cy + b.ey >= y0 + T(0.5)) && (b.cy - b.ey <= y0 + T(7.5));
 }
 
+// ---- antialiased pdf, float: v_exp_f32 / v_rcp_f32 and the staged 1/sigma instead of expf and divisions
+// (generic.py:341-404; the double instantiation keeps the exact formulation of splat_math.h)
+__device__ __forceinline__ float aa_sigmoid(float x, float inv_sigma, float& z) {
+  z = x * inv_sigma;
+  // exp(-(1.6 z + 0.07 z^3)) = exp2(z (-1.6 log2e - 0.07 log2e z^2))
+  const float e = __builtin_amdgcn_exp2f(z * (-2.30831206544f - 0.100988652863f * z * z));
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int F>
+__device__ __forceinline__ float aa_pdf(const Splat<float, F>& s, float px, float py) {
+  const float dx = px - s.mx, dy = py - s.my;
+  const float tx = dx * s.ax + dy * s.ay, ty = dy * s.ax - dx * s.ay;
+  float z;
+  const float ix = aa_sigmoid(tx + 0.5f, s.isx, z) - aa_sigmoid(tx - 0.5f, s.isx, z);
+  const float iy = aa_sigmoid(ty + 0.5f, s.isy, z) - aa_sigmoid(ty - 0.5f, s.isy, z);
+  return 6.283185307179586f * (s.sx * ix) * (s.sy * iy);
+}
+
+template <int F>
+__device__ __forceinline__ double aa_pdf(const Splat<double, F>& s, double px, double py) {
+  const double g[6] = {s.mx, s.my, s.ax, s.ay, s.sx, s.sy};
+  return gaussian_pdf_antialias(px, py, g);
+}
+
+template <int F>
+__device__ __forceinline__ float aa_pdf_with_grad(const Splat<float, F>& s, float px, float py, float gm[2],
+                                                  float ga[2], float gs[2]) {
+  const float dx = px - s.mx, dy = py - s.my;
+  const float tx = dx * s.ax + dy * s.ay, ty = dy * s.ax - dx * s.ay;
+  // S, dS/dx and dS/dsigma at the four cell edges (generic.py:360-368)
+  float S[4], dS[4], dSs[4];
+  const float xs[4] = {tx + 0.5f, tx - 0.5f, ty + 0.5f, ty - 0.5f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float inv = k < 2 ? s.isx : s.isy;
+    float z;
+    S[k] = aa_sigmoid(xs[k], inv, z);
+    const float d = (1.6f + 0.21f * z * z) * S[k] * (1.0f - S[k]);
+    dS[k] = d * inv;
+    dSs[k] = -dS[k] * z;
+  }
+  const float tau = 6.283185307179586f;
+  const float ix = s.sx * (S[0] - S[1]), iy = s.sy * (S[2] - S[3]);
+  const float dSx = iy * s.sx * (dS[0] - dS[1]), dSy = ix * s.sy * (dS[2] - dS[3]);
+  gm[0] = tau * (dSy * s.ay - dSx * s.ax);
+  gm[1] = -tau * (dSx * s.ay + dSy * s.ax);
+  gs[0] = tau * iy * (S[0] - S[1] + (dSs[0] - dSs[1]) * s.sx);
+  gs[1] = tau * ix * (S[2] - S[3] + (dSs[2] - dSs[3]) * s.sy);
+  ga[0] = tau * (dSx * dx + dSy * dy);
+  ga[1] = tau * (dSx * dy - dSy * dx);
+  return tau * ix * iy;
+}
+
+template <int F>
+__device__ __forceinline__ double aa_pdf_with_grad(const Splat<double, F>& s, double px, double py, double gm[2],
+                                                   double ga[2], double gs[2]) {
+  const double g[6] = {s.mx, s.my, s.ax, s.ay, s.sx, s.sy};
+  return gaussian_pdf_antialias_with_grad(px, py, g, gm, ga, gs);
+}
+
 template <typename T, int F, bool AA>
 __device__ __forceinline__ T splat_pdf(const Splat<T, F>& s, T px, T py) {
   if (AA) {
-    const T g[6] = {s.mx, s.my, s.ax, s.ay, s.sx, s.sy};
-    return gaussian_pdf_antialias(px, py, g);
+    return aa_pdf<F>(s, px, py);
   } else {
     const T dx = px - s.mx, dy = py - s.my;
     const T X = dx * s.A + dy * s.B;
@@ -151,7 +232,7 @@ raster_fwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
   for (int begin = start; begin < end; begin += BATCH) {
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     __syncthreads();   // previous batch fully consumed
-    stage_batch<T, F, BATCH>(points, feats, o2p, begin, count, rp.alpha_threshold, !AA, s_splat, s_cull, s_id);
+    stage_batch<T, F, BATCH>(points, feats, o2p, begin, count, rp.alpha_threshold, AA, s_splat, s_cull, s_id);
     __syncthreads();
 
     for (int r = 0; r < count; r += 64) {
@@ -304,7 +385,7 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     // tile-wide early out once every pixel is saturated (backward.py:116)
     if (__syncthreads_and(W >= rp.saturate_threshold)) break;
-    stage_batch<T, F, BATCH>(points, feats, o2p, begin, count, rp.alpha_threshold, !AA, s_splat, s_cull, s_id);
+    stage_batch<T, F, BATCH>(points, feats, o2p, begin, count, rp.alpha_threshold, AA, s_splat, s_cull, s_id);
     __syncthreads();
 
     // wave-wide early out (backward.py:142)
@@ -325,8 +406,7 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
         T gm[2], ga[2], gs[2];
         T p;
         if (AA) {
-          const T g[6] = {s.mx, s.my, s.ax, s.ay, s.sx, s.sy};
-          p = gaussian_pdf_antialias_with_grad(px, py, g, gm, ga, gs);
+          p = aa_pdf_with_grad<F>(s, px, py, gm, ga, gs);
         } else {
           const T dx = px - s.mx, dy = py - s.my;
           const T X = dx * s.A + dy * s.B;

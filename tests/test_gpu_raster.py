@@ -232,6 +232,38 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
     assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
 
 
+@pytest.mark.parametrize('tile_size,n,size,scale,alpha', [(16, 20000, (333, 200), 1.0, (0.1, 0.9)), (8, 6000, (96, 64), 5.0, (0.5, 1.0)),
+                                                          (32, 100000, (640, 480), 1.5, (0.02, 0.9))])
+def test_f32_antialias_matches_f64(tile_size, n, size, scale, alpha):
+  # antialiased pdf: the float kernels use v_exp_f32 / v_rcp_f32 and the contribution-rectangle cull; the f64
+  # instantiation (exact formulation, checked against the oracle above) is the reference
+  torch.manual_seed(n)
+  cfg = cfg_for(tile_size, antialias=True, compute_point_heuristic=True, compute_visibility=True)
+  g = random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha).to(DEV)
+  p32 = project_gaussians2d(g)
+  o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
+  ranges = ranges.view(-1, 2)
+  torch.manual_seed(1)
+  G = torch.randn(size[1], size[0], 3, device=DEV)
+  res = {}
+  for dtype in (torch.float64, torch.float32):
+    p = p32.to(dtype).clone().requires_grad_(True)
+    f = g.feature.to(dtype).clone().requires_grad_(True)
+    out = rasterize_with_tiles(p, f, o2p, ranges, size, cfg)
+    (out.image * G.to(dtype)).sum().backward()
+    res[dtype] = (out.image.detach().double(), p.grad.double(), f.grad.double(), out.point_heuristic.double(),
+                  out.visibility.double())
+  img64, img32 = res[torch.float64][0], res[torch.float32][0]
+  err = (img32 - img64).abs().max(-1).values
+  assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2, (err.quantile(0.9999), err.max())
+  assert res[torch.float64][1].abs().sum() > 0
+  for got, want in zip(res[torch.float32][1:], res[torch.float64][1:]):
+    scale_ = want.abs().max().item() + 1e-12
+    rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
+    assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
+    assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
+
+
 @pytest.mark.parametrize('mode,heur,tile_size,n,size,scale', [
     ('sub', True, 16, 60000, (500, 300), 1.2),
     ('pairs', False, 16, 60000, (500, 300), 1.2),
