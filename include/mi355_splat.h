@@ -197,6 +197,19 @@ int ms_fractional_step(int kind, int vector, float* lr_step, const int64_t* inde
                        const float* grad, int64_t m_count, int d, float lr, float beta1,
                        float beta2, float eps, int bias_correction, void* stream);
 
+/* Fused per-group update (optim/fractional.py:108-156,176-195 + the gradient pre-scaling of
+ * optim/visibility_aware.py:95-104) for the m_count visible rows listed in indexes, in one pass:
+ *   g = grad[idx] * grad_scale[i];  local_vector (group_type 2, d = 2 or 3): g = basis[i]^-1 g;
+ *   moments m / v updated as in ms_fractional_step (group_type 0: v is (N,D); 1, 2: v is (N,));
+ *   step clamped to +-lr*clip (clip < 0: off); local_vector: step = basis[i] step; *= mask_lr[j];
+ *   *= point_lr[idx]; non-finite -> 0;  param[idx] -= step * (1 - exp(-2 weight[i])).
+ * grad_scale (m_count), basis (m_count, d, d), mask_lr (d), point_lr (N) may be NULL.  float32, d <= 256. */
+int ms_fractional_update(int kind, int group_type, float* param, const float* grad, float* m, float* v,
+                         const int64_t* indexes, const float* weight, const float* total_weight,
+                         const float* grad_scale, const float* basis, const float* mask_lr,
+                         const float* point_lr, int64_t m_count, int d, float lr, float beta1,
+                         float beta2, float eps, float clip, int bias_correction, void* stream);
+
 /* ---- Morton codes --------------------------------------------------------------------
  * out_codes[i] = 63-bit Z-order code of points3[i] (N, 3 float32) on the grid of cell size inc3_host anchored at
  * lower3_host (3 floats each, host memory) with `size` cells per axis (<= 2^21): cell = clamp((p - lower) / inc,

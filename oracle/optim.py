@@ -38,3 +38,30 @@ def fractional_step(kind, vector, indexes, weight, m, v, total_weight, grad, lr,
   m[indexes] = m_new
   v[indexes] = v_new.squeeze(1) if vector else v_new
   return step
+
+
+def group_update(kind, group_type, param, grad, m, v, indexes, weight, total_weight, lr, betas, eps,
+                 bias_correction, grad_scale=None, basis=None, clip=None, mask_lr=None, point_lr=None):
+  """One parameter group's step on the visible rows, host logic of optim/fractional.py:108-156,190-195
+  (``weighted_step`` + ``param[indexes] -= lr_step * saturate(weight)``) with the gradient pre-scaling of
+  optim/visibility_aware.py:95-104 (``grad_scale`` = 1 / (visibility + vis_smooth)).  Updates param, m, v
+  in place.  group_type: 'scalar' | 'vector' | 'local_vector'."""
+  grad = grad.clone()
+  if grad_scale is not None:
+    grad[indexes] = grad[indexes] * grad_scale.unsqueeze(1)
+  if group_type == 'local_vector':
+    inv_basis = torch.linalg.inv(basis)
+    grad[indexes] = torch.einsum('bij,bj->bi', inv_basis, grad[indexes])
+  step = fractional_step(kind, group_type != 'scalar', indexes, weight, m, v, total_weight, grad, lr, betas, eps,
+                         bias_correction)
+  if clip is not None:
+    step = step.clamp(-lr * clip, lr * clip)
+  if group_type == 'local_vector':
+    step = torch.einsum('bij,bj->bi', basis, step)
+  if mask_lr is not None:
+    step = step * mask_lr.view(-1).unsqueeze(0)
+  if point_lr is not None:
+    step = step * point_lr[indexes].unsqueeze(1)
+  step = torch.where(torch.isfinite(step), step, torch.zeros_like(step))
+  param[indexes] -= step * (1 - 1 / torch.exp(2 * weight)).unsqueeze(1)
+  return step

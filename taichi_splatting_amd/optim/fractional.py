@@ -102,6 +102,50 @@ def weighted_step(group: Group, visible_weight: torch.Tensor, visible_indexes: t
   return lr_step
 
 
+GROUP_TYPES = {"scalar": 0, "vector": 1, "local_vector": 2}
+
+
+def fused_update(group: Group, visible_weight: torch.Tensor, visible_indexes: torch.Tensor,
+                 total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None,
+                 grad_scale: Optional[torch.Tensor] = None):
+  """The whole per-group step — ``weighted_step`` + ``param[indexes] -= lr_step * saturate(weight)``
+  (reference optim/fractional.py:108-156,190-195) — as ONE kernel, ``ms_fractional_update``."""
+  if group.type not in GROUP_TYPES:
+    raise ValueError(f"unknown group type {group.type}")
+  if group.type == "scalar":
+    m, v = get_scalar_state(group.state, group.param)
+  else:
+    m, v = get_vector_state(group.state, group.param)
+  if group.type == "local_vector":
+    assert basis is not None, "basis is required for local_vector optimizer"
+    d = group.param.shape[1]
+    assert tuple(basis.shape) == (visible_indexes.shape[0], d, d), f"basis must be (M, {d}, {d}), got {tuple(basis.shape)}"
+    basis = basis.detach().to(torch.float32).contiguous()
+  else:
+    basis = None
+
+  lib = _lib.load()
+  param, grad = group.param, group.grad
+  _lib.require_gpu(param, grad, visible_indexes, visible_weight, total_weight)
+  assert param.is_contiguous() and param.dtype == torch.float32, "fractional optimisers run in contiguous float32"
+  grad = grad.contiguous()
+  indexes = visible_indexes.contiguous()
+  weight = visible_weight.to(torch.float32).contiguous()
+  assert indexes.dtype == torch.int64
+  gs = grad_scale.to(torch.float32).contiguous() if grad_scale is not None else None
+  mask_lr = group.mask_lr.to(device=param.device, dtype=torch.float32).reshape(-1).contiguous() if group.mask_lr is not None else None
+  if mask_lr is not None:
+    assert mask_lr.shape[0] == param.shape[1], f"mask_lr must have {param.shape[1]} entries"
+  point_lr = group.point_lr.to(torch.float32).contiguous() if group.point_lr is not None else None
+  _lib.check(lib.ms_fractional_update(kind, GROUP_TYPES[group.type], _lib.ptr(param), _lib.ptr(grad), _lib.ptr(m), _lib.ptr(v),
+                                      _lib.ptr(indexes), _lib.ptr(weight), _lib.ptr(total_weight), _lib.ptr(gs),
+                                      _lib.ptr(basis), _lib.ptr(mask_lr), _lib.ptr(point_lr), indexes.shape[0],
+                                      param.shape[1], float(group.lr), float(group.betas[0]), float(group.betas[1]),
+                                      float(group.eps), float(group.clip) if group.clip is not None else -1.0,
+                                      int(group.bias_correction), _lib.current_stream(param.device)),
+             "fractional optimizer update")
+
+
 def saturate(x: torch.Tensor):
   return 1 - 1 / torch.exp(2 * x)
 
@@ -131,8 +175,7 @@ class FractionalOpt(torch.optim.Optimizer):
       if group.grad is None:
         continue
       assert group.num_points == n, f"param shape {group.num_points} != {n}"
-      lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis)
-      group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
+      fused_update(group, weight, indexes, total_weight, self.kind, basis)
 
 
 class FractionalAdam(FractionalOpt):

@@ -8,7 +8,7 @@ from typing import Optional
 
 import torch
 
-from .fractional import ADAM, LAPROP, make_group, saturate, weighted_step
+from .fractional import ADAM, LAPROP, fused_update, make_group, saturate, weighted_step  # noqa: F401
 from .util import get_running_vis, get_total_weight
 
 
@@ -60,14 +60,13 @@ class VisibilityOptimizer(torch.optim.Optimizer):
     weight = update_visibility(running_vis, visibility, indexes, total_weight, self.vis_beta)
     total_weight[indexes] += weight
 
+    grad_scale = 1.0 / (visibility + self.vis_smooth)
     for group in groups:
       if group.grad is None:
         continue
       assert group.num_points == n, f"param shape {group.num_points} != {n}"
-      group = replace(group, grad=set_indexes(
-        group.grad, group.grad[indexes] / (visibility.unsqueeze(1) + self.vis_smooth), indexes))
-      lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis)
-      group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
+      # gradients are normalised by the point's visibility (reference :95-104): fused as a row scale
+      fused_update(group, weight, indexes, total_weight, self.kind, basis, grad_scale=grad_scale)
 
 
 class VisibilityAwareAdam(VisibilityOptimizer):
