@@ -90,6 +90,7 @@ struct UpdateArgs {
   const float* point_lr;
   int64_t m_count; int d; float lr, beta1, beta2, eps, clip; int bias_correction;
   float log2_beta1, log2_beta2;      // beta^w = exp2(w log2 beta): v_exp_f32 instead of powf
+  float* out_step;                   // ms_fractional_step: write the raw step (M, D) instead of updating param
 };
 
 template <int LPP>
@@ -221,6 +222,7 @@ fractional_update_kernel(UpdateArgs a) {
     if (live && j < d) {
       float sj = step[k] * plr;
       if (a.mask_lr) sj *= a.mask_lr[j];
+      if (a.out_step) { a.out_step[i * d + j] = sj; continue; }
       if (!(fabsf(sj) < 3.0e38f)) sj = 0.f;          // non-finite -> 0 (fractional.py:153)
       a.param[idx * d + j] -= sj * sat;
     }
@@ -231,6 +233,28 @@ fractional_update_kernel(UpdateArgs a) {
 
 using namespace ms;
 
+static int launch_update(int kind, int group_type, const UpdateArgs& a, hipStream_t s) {
+  const int d = a.d;
+  const int64_t m_count = a.m_count;
+  const int shape = group_type == 2 ? 1 : (d == 1 ? 0 : d <= 4 ? 1 : d <= 16 ? 2 : d <= 64 ? 3 : 4);
+  const int lpp = shape == 0 ? 1 : shape == 1 ? 4 : 16;
+  const dim3 block(256), grid((unsigned)div_up(m_count * lpp, 256));
+#define MS_GO(K, T, L, KM) fractional_update_kernel<K, T, L, KM><<<grid, block, 0, s>>>(a)
+#define MS_LPP(K, T)                                                                                    \
+  switch (shape) { case 0: MS_GO(K, T, 1, 1); break; case 1: MS_GO(K, T, 4, 1); break;                  \
+                   case 2: MS_GO(K, T, 16, 1); break; case 3: MS_GO(K, T, 16, 4); break;                \
+                   default: MS_GO(K, T, 16, 16); break; }
+  if (kind == 0) {
+    if (group_type == 0) { MS_LPP(0, 0) } else if (group_type == 1) { MS_LPP(0, 1) } else { MS_GO(0, 2, 4, 1); }
+  } else {
+    if (group_type == 0) { MS_LPP(1, 0) } else if (group_type == 1) { MS_LPP(1, 1) } else { MS_GO(1, 2, 4, 1); }
+  }
+#undef MS_LPP
+#undef MS_GO
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int ms_fractional_step(int kind, int vector, float* lr_step, const int64_t* indexes,
                                   const float* weight, float* m, float* v, const float* total_weight,
                                   const float* grad, int64_t m_count, int d, float lr, float beta1,
@@ -239,6 +263,12 @@ extern "C" int ms_fractional_step(int kind, int vector, float* lr_step, const in
   MS_CHECK_ARG(m_count >= 0 && d >= 1, "bad sizes");
   if (m_count == 0) return 0;
   MS_CHECK_ARG(lr_step && indexes && weight && m && v && total_weight && grad, "null pointer");
+  if (d <= 256) {       // the cooperative (coalesced) kernel of ms_fractional_update, writing the raw step
+    UpdateArgs a{nullptr, grad, m, v, indexes, weight, total_weight, nullptr, nullptr, nullptr, nullptr,
+                 m_count, d, lr, beta1, beta2, eps, -1.0f, bias_correction,
+                 (float)log2((double)beta1), (float)log2((double)beta2), lr_step};
+    return launch_update(kind, vector ? 1 : 0, a, (hipStream_t)stream);
+  }
   const dim3 block(256), grid((unsigned)div_up(m_count, 256));
   hipStream_t s = (hipStream_t)stream;
 #define MS_GO(K, V) fractional_step_kernel<K, V><<<grid, block, 0, s>>>(lr_step, indexes, weight, m, v, total_weight, grad, m_count, d, lr, beta1, beta2, eps, bias_correction)
@@ -265,23 +295,6 @@ extern "C" int ms_fractional_update(int kind, int group_type, float* param, cons
   }
   UpdateArgs a{param, grad, m, v, indexes, weight, total_weight, grad_scale, basis, mask_lr, point_lr,
                m_count, d, lr, beta1, beta2, eps, clip, bias_correction,
-               (float)log2((double)beta1), (float)log2((double)beta2)};
-  hipStream_t s = (hipStream_t)stream;
-  const int shape = group_type == 2 ? 1 : (d == 1 ? 0 : d <= 4 ? 1 : d <= 16 ? 2 : d <= 64 ? 3 : 4);
-  const int lpp = shape == 0 ? 1 : shape == 1 ? 4 : 16;
-  const dim3 block(256), grid((unsigned)div_up(m_count * lpp, 256));
-#define MS_GO(K, T, L, KM) fractional_update_kernel<K, T, L, KM><<<grid, block, 0, s>>>(a)
-#define MS_LPP(K, T)                                                                                    \
-  switch (shape) { case 0: MS_GO(K, T, 1, 1); break; case 1: MS_GO(K, T, 4, 1); break;                  \
-                   case 2: MS_GO(K, T, 16, 1); break; case 3: MS_GO(K, T, 16, 4); break;                \
-                   default: MS_GO(K, T, 16, 16); break; }
-  if (kind == 0) {
-    if (group_type == 0) { MS_LPP(0, 0) } else if (group_type == 1) { MS_LPP(0, 1) } else { MS_GO(0, 2, 4, 1); }
-  } else {
-    if (group_type == 0) { MS_LPP(1, 0) } else if (group_type == 1) { MS_LPP(1, 1) } else { MS_GO(1, 2, 4, 1); }
-  }
-#undef MS_LPP
-#undef MS_GO
-  MS_CHECK_LAUNCH();
-  return 0;
+               (float)log2((double)beta1), (float)log2((double)beta2), nullptr};
+  return launch_update(kind, group_type, a, (hipStream_t)stream);
 }
