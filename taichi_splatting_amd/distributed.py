@@ -268,6 +268,9 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
                        exchange=_all_to_all):
   """Route this rank's projected splats to the strips they can overlap.
 
+  ``features`` is the (V, F) colour tensor or a callable returning it (evaluated after the routing kernels
+  are queued, so that it overlaps the split-size synchronisation).
+
   Returns (gaussians2d, features, depths, global_index) of the splats RECEIVED for this rank's strip,
   grouped by source rank and in source order; gaussians2d / features stay attached to the autograd
   graph (the backward pass sends their gradients home and sums them per splat).  Global id of local
@@ -277,9 +280,9 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
   kernels); other inputs (float64 gradcheck-style tests, CPU tensors under gloo) the equivalent torch
   formulation below."""
   world = len(bounds) - 1
-  n, f = gaussians2d.shape[0], features.shape[1]
-  g2d, feats, dep = gaussians2d.detach().contiguous(), features.detach().contiguous(), depths.detach().reshape(-1).contiguous()
-  kernels = _use_kernels(g2d) and feats.dtype == torch.float32 and dep.dtype == torch.float32
+  n = gaussians2d.shape[0]
+  g2d, dep = gaussians2d.detach().contiguous(), depths.detach().reshape(-1).contiguous()
+  kernels = _use_kernels(g2d) and dep.dtype == torch.float32
   if kernels:
     from . import _lib
     lib = _lib.load()
@@ -298,8 +301,14 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
     lo, hi = splat_row_span(g2d, image_size, config)
     first, copies, send_counts_t = route_to_strips(lo, hi, bounds)
 
-  # split sizes: one tiny all-to-all + ONE host synchronisation
+  # split sizes: one tiny all-to-all + ONE host synchronisation.  The colours are not needed for the routing:
+  # a callable ``features`` is evaluated now, so that its kernels run while the host waits for the counts
   recv_counts_t = exchange(send_counts_t.view(world, 1), [1] * world, [1] * world, group)
+  if callable(features):
+    features = features()
+  f = features.shape[1]
+  feats = features.detach().contiguous()
+  assert not kernels or feats.dtype == torch.float32, "features must be float32 like the packed gaussians"
   send_counts, recv_counts = torch.stack([send_counts_t, recv_counts_t.view(world)]).tolist()
   total = int(sum(send_counts))
 
@@ -347,11 +356,12 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1
 
   gaussians2d, depths, indexes = project_to_image(shard, camera_params, config)
-  if use_sh:
-    features = evaluate_sh_at(shard.feature, shard.position.detach(), indexes, camera_params.camera_position,
-                              unique_indexes=True)
-  else:
-    features = shard.feature[indexes]
+
+  def features():
+    if use_sh:
+      return evaluate_sh_at(shard.feature, shard.position.detach(), indexes, camera_params.camera_position,
+                            unique_indexes=True)
+    return shard.feature[indexes]
 
   ts = config.tile_size
   tiles_high = (camera_params.image_size[1] + ts - 1) // ts
