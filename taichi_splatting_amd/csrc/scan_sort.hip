@@ -102,6 +102,43 @@ scan_downsweep_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* 
   }
 }
 
+// Two-launch variant for up to SCAN_SELF_MAX_BLOCKS tiles: every block sums the totals of the tiles before
+// it itself (<= 32 KB of L2-resident reads) instead of waiting for a single-workgroup spine launch; the last
+// block also writes the grand total.  Saves one dependent launch (~5 us) per scan: the frame runs eight.
+constexpr int64_t SCAN_SELF_MAX_BLOCKS = 8192;
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_downsweep_self_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ block_sums,
+                           int32_t* __restrict__ out, int32_t* __restrict__ total_host) {
+  __shared__ int lds[4];
+  int before = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += block_sums[j];
+  int block_prefix;
+  block_exclusive_scan(before, lds, &block_prefix);
+
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int vals[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int64_t i = base + k;
+    vals[k] = i < n ? in[i] : 0;
+    s += vals[k];
+  }
+  int total;
+  int prefix = block_exclusive_scan(s, lds, &total) + block_prefix;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int64_t i = base + k;
+    if (i < n) out[i] = prefix;
+    prefix += vals[k];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    out[n] = block_prefix + total;
+    if (total_host) *total_host = block_prefix + total;
+  }
+}
+
 static size_t scan_tmp_bytes(int64_t n) { return align_up((size_t)div_up(n > 0 ? n : 1, SCAN_TILE) * sizeof(int32_t), 256); }
 
 // out has n + 1 entries (out[n] = total).  in and out may NOT alias unless identical ranges are
@@ -111,6 +148,10 @@ static int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_
   const int64_t blocks = div_up(n, SCAN_TILE);
   int32_t* block_sums = (int32_t*)tmp;
   scan_block_sums_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums);
+  if (blocks <= SCAN_SELF_MAX_BLOCKS) {
+    scan_downsweep_self_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out, total_host);
+    return 0;
+  }
   scan_spine_kernel<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(block_sums, blocks, out + n, total_host);
   scan_downsweep_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out);
   return 0;
