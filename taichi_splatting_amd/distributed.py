@@ -239,6 +239,24 @@ class _StripExchange(torch.autograd.Function):
     return grad[:, :7].contiguous(), grad[:, 7:].contiguous(), None, None, None, None, None, None, None
 
 
+class ExchangePlan:
+  """What one forward exchange decided: reusable to send per-splat rows of the strip back to their owners."""
+
+  def __init__(self, send_index, route, send_counts, recv_counts, group, exchange, n):
+    self.send_index, self.route, self.send_counts, self.recv_counts = send_index, route, send_counts, recv_counts
+    self.group, self.exchange, self.n = group, exchange, n
+
+
+def return_to_owners(plan: ExchangePlan, rows: torch.Tensor) -> torch.Tensor:
+  """Send per-received-splat rows (M, k) (e.g. visibility, split heuristics accumulated on the strip) home
+  through the reverse all-to-all and sum the copies of each local splat: (V_local, k).  Not differentiable."""
+  with torch.no_grad():
+    back = plan.exchange(rows.detach().contiguous(), plan.recv_counts, plan.send_counts, plan.group)
+    out = back.new_zeros((plan.n, rows.shape[1]))
+    out.index_add_(0, plan.send_index, back)
+  return out
+
+
 FORCE_TORCH_ROUTING = False      # tests: compare the HIP routing kernels with the torch formulation
 
 
@@ -265,7 +283,7 @@ def _split_rows(recv: torch.Tensor, f: int):
 def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths: torch.Tensor,
                        image_size: Tuple[int, int], config: RasterConfig, bounds: Sequence[int],
                        global_index: Optional[torch.Tensor] = None, index_offset: int = 0, group=None,
-                       exchange=_all_to_all):
+                       exchange=_all_to_all, return_plan: bool = False):
   """Route this rank's projected splats to the strips they can overlap.
 
   ``features`` is the (V, F) colour tensor or a callable returning it (evaluated after the routing kernels
@@ -329,14 +347,18 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
 
   g2, f2, d, gid = _StripExchange.apply(gaussians2d, features, rows, send_index, route if kernels else None,
                                         send_counts, recv_counts, group, exchange)
-  return g2, f2, d.reshape((-1,) + tuple(depths.shape[1:])), gid
+  d = d.reshape((-1,) + tuple(depths.shape[1:]))
+  if return_plan:
+    return g2, f2, d, gid, ExchangePlan(send_index, route if kernels else None, send_counts, recv_counts, group, exchange, n)
+  return g2, f2, d, gid
 
 
 def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
                         loss_fn: Callable[[torch.Tensor, Tuple[int, int]], torch.Tensor],
                         use_sh: bool = False, rank: Optional[int] = None, world_size: Optional[int] = None,
                         group=None, backward: bool = True, index_offset: int = 0,
-                        bounds: Optional[Sequence[int]] = None, exchange=_all_to_all):
+                        bounds: Optional[Sequence[int]] = None, exchange=_all_to_all,
+                        point_stats: Optional[dict] = None):
   """One forward(+backward) step with gaussians sharded by index and pixels sharded by tile-row strip.
 
   ``shard`` holds only this rank's gaussians (``index_offset`` = global index of its first one).
@@ -345,6 +367,11 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
   allocates or touches the full frame).  After the call ``.grad`` of the leaf tensors of ``shard`` is the complete gradient of the
   summed loss for those gaussians.  Returns (Rendering of the strip, loss value of the strip); the
   ``points`` of the rendering are the splats received for the strip, ``points.idx`` their global ids.
+
+  ``point_stats``: a dict to fill with what the densification / visibility-aware optimisers need for the
+  OWNED gaussians, summed over all strips and sent home with one more reverse all-to-all: ``'visibility'``
+  (N_shard,) when ``config.compute_visibility``, ``'point_heuristic'`` (N_shard, 2) when
+  ``config.compute_point_heuristic`` (zeros for gaussians that were not visible).
   """
   from .perspective.projection import project_to_image
   from .renderer import render_projected
@@ -369,9 +396,9 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
     bounds = strip_bounds(tiles_high, world_size)
   rows = (bounds[rank], bounds[rank + 1])
 
-  g2, f2, d, gid = exchange_to_strips(gaussians2d, features, depths, camera_params.image_size, config, bounds,
-                                      global_index=indexes, index_offset=index_offset, group=group,
-                                      exchange=exchange)
+  g2, f2, d, gid, plan = exchange_to_strips(gaussians2d, features, depths, camera_params.image_size, config, bounds,
+                                            global_index=indexes, index_offset=index_offset, group=group,
+                                            exchange=exchange, return_plan=True)
   rendering = render_projected(gid, g2, f2, d, camera_params, config, tile_rows=rows, crop_to_rows=True)
 
   h = camera_params.image_size[1]
@@ -379,6 +406,23 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
   loss = loss_fn(rendering.image, px_rows)
   if backward and loss.requires_grad:
     loss.backward()
+
+  if point_stats is not None and (config.compute_visibility or config.compute_point_heuristic):
+    # after the backward pass: the split heuristics are accumulated there
+    cols = []
+    if config.compute_visibility:
+      cols.append(rendering.points.visibility.reshape(-1, 1))
+    if config.compute_point_heuristic:
+      cols.append(torch.stack([rendering.points.prune_cost, rendering.points.split_score], dim=1))
+    home = return_to_owners(plan, torch.cat(cols, dim=1).to(g2.dtype))
+    full = home.new_zeros((shard.position.shape[0], home.shape[1]))
+    full[indexes] = home
+    k = 0
+    if config.compute_visibility:
+      point_stats['visibility'] = full[:, 0]
+      k = 1
+    if config.compute_point_heuristic:
+      point_stats['point_heuristic'] = full[:, k:k + 2]
   return rendering, loss.detach()
 
 

@@ -39,7 +39,7 @@ def _worker(rank, world, port, dtype_name, balance, ret):
     g = random_3d_gaussians(n, cam, scale_factor=1.5, alpha_range=(0.1, 0.9))
     g = g.replace(feature=(torch.rand(n, 3, 16) - 0.5) * 0.5).to(dtype=dtype)
     cam = cam.to(device=DEV, dtype=dtype)
-    cfg = RasterConfig()
+    cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
     torch.manual_seed(0)
     G = torch.randn(size[1], size[0], 3, dtype=dtype, device=DEV)
 
@@ -49,7 +49,7 @@ def _worker(rank, world, port, dtype_name, balance, ret):
     shard = g[b:e].to(DEV).requires_grad_(True)
     rendering, _ = render_sharded_step(shard, cam, cfg, lambda img, px: (img * G[px[0]:px[1]]).sum(), use_sh=True,
                                        rank=rank, world_size=world, index_offset=b, bounds=bounds,
-                                       exchange=all_to_all_via_host)
+                                       exchange=all_to_all_via_host, point_stats=(stats := {}))
 
     full = g.to(DEV).requires_grad_(True)
     r = render_gaussians(full, cam, cfg, use_sh=True)
@@ -69,6 +69,13 @@ def _worker(rank, world, port, dtype_name, balance, ret):
       err = ((got - want).abs().max() / scale).item()
       worst = max(worst, err)
       ok = ok and err < (1e-8 if dtype == torch.float64 else 2e-3)
+    # visibility / split heuristics of the OWNED gaussians, summed over the strips and sent home
+    vis_full = torch.zeros(n, dtype=dtype, device=DEV); vis_full[r.points.idx] = r.points.visibility
+    heur_full = torch.zeros(n, 2, dtype=dtype, device=DEV)
+    heur_full[r.points.idx] = torch.stack([r.points.prune_cost, r.points.split_score], dim=1)
+    stol = dict(rtol=1e-6, atol=1e-9) if dtype == torch.float64 else dict(rtol=2e-3, atol=1e-4 * float(heur_full.abs().max()))
+    ok = ok and torch.allclose(stats['visibility'], vis_full[b:e], rtol=stol['rtol'], atol=1e-5 if dtype == torch.float32 else 1e-9)
+    ok = ok and torch.allclose(stats['point_heuristic'], heur_full[b:e], **stol) and float(vis_full[b:e].sum()) > 0
     ret[rank] = (bool(ok), worst)
   finally:
     dist.destroy_process_group()
