@@ -128,7 +128,7 @@ def test_routing_kernels_match_torch_formulation(world, bounds):
 
 
 @pytest.mark.parametrize('world,dtype_name,balance', [(2, 'float64', False), (3, 'float64', True), (4, 'float32', False),
-                                                      (3, 'float32', True)])
+                                                      (3, 'float32', True), (8, 'float32', False)])
 def test_sharded_step_matches_full_frame(world, dtype_name, balance):
   port = _free_port()
   mgr = mp.Manager()
