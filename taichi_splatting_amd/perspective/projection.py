@@ -49,6 +49,10 @@ def _project_forward(position, log_scaling, rotation, alpha_logit, T_camera_worl
                                        ctypes.byref(nbytes), stream), "project_to_image")
   v = int(scan[n].item())   # host sync: V sizes the outputs (the reference syncs in torch.nonzero)
 
+  if v == n and not with_ndc:
+    # every gaussian is visible: the uncompacted arrays ARE the result, no gather pass
+    return points_full, depth_full.unsqueeze(1), torch.arange(n, dtype=torch.int64, device=device), None
+
   points = torch.empty((v, 7), dtype=dtype, device=device)
   depth = torch.empty((v, 1), dtype=dtype, device=device)
   ndc = torch.empty((v, 1), dtype=dtype, device=device) if with_ndc else None
