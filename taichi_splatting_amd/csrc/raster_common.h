@@ -32,12 +32,15 @@ __device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const 
 
 // LDS records of one splat: blend record [mx my A B] [C D alpha f0] [f1 f2 isx isy] and cull record
 // [cx cy ex ey] [A' B' C' D'] (inverse basis divided by the cutoff radius)
-__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull) {
+// basis_scale: the blend record's A..D are multiplied by it (the forward kernel stores them pre-scaled by
+// sqrt(log2(e) / 2) so that g = exp2(-(X^2 + Y^2)) needs no extra multiply; the backward needs the true X, Y)
+__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull,
+                                              float basis_scale = 1.0f) {
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
   const float isx = 1.0f / sx, isy = 1.0f / sy;
   const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
-  rec[0] = make_float4(mx, my, A, B);
-  rec[1] = make_float4(C, D, alpha, r.f[0]);
+  rec[0] = make_float4(mx, my, A * basis_scale, B * basis_scale);
+  rec[1] = make_float4(C * basis_scale, D * basis_scale, alpha, r.f[0]);
   rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
   // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
   // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
@@ -116,6 +119,7 @@ __device__ __forceinline__ float min_f32(float a, float b) {
 }
 
 constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
+constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
 
 template <int TS> struct TileGeom {
   static constexpr int THREADS = TS * TS;
