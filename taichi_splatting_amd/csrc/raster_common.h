@@ -30,17 +30,22 @@ __device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const 
   return r;
 }
 
+constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
+constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
+
 // LDS records of one splat: blend record [mx my A B] [C D alpha f0] [f1 f2 isx isy] and cull record
 // [cx cy ex ey] [A' B' C' D'] (inverse basis divided by the cutoff radius)
-// basis_scale: the blend record's A..D are multiplied by it (the forward kernel stores them pre-scaled by
-// sqrt(log2(e) / 2) so that g = exp2(-(X^2 + Y^2)) needs no extra multiply; the backward needs the true X, Y)
-__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull,
-                                              float basis_scale = 1.0f) {
+// FWD_FORM (forward kernel): A..D are stored pre-scaled by sqrt(log2(e) / 2) and the alpha slot holds
+// -log2(alpha), so that alpha * g = exp2(-(X^2 + Y^2 - log2 alpha)) is two FMAs and one v_exp_f32; the
+// backward needs the true X, Y and g and keeps the plain form.
+template <bool FWD_FORM = false>
+__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull) {
+  const float basis_scale = FWD_FORM ? EXP2_BASIS_SCALE : 1.0f;
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
   const float isx = 1.0f / sx, isy = 1.0f / sy;
   const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
   rec[0] = make_float4(mx, my, A * basis_scale, B * basis_scale);
-  rec[1] = make_float4(C * basis_scale, D * basis_scale, alpha, r.f[0]);
+  rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -log2f(alpha) : alpha, r.f[0]);
   rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
   // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
   // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
@@ -118,8 +123,6 @@ __device__ __forceinline__ float min_f32(float a, float b) {
   return r;
 }
 
-constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
-constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
 
 template <int TS> struct TileGeom {
   static constexpr int THREADS = TS * TS;

@@ -83,7 +83,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       s_vis[t] = 0.0f;
     }
     if (stager && begin + t < end) {
-      write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2], EXP2_BASIS_SCALE);
+      write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
       if (VIS) s_id[t] = raw.id;
     }
     if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
@@ -121,8 +121,8 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const float dx = px - q0.x, dy = py - q0.y;
         const float X = dx * q0.z + dy * q0.w;
         const float Y = dx * q1.x + dy * q1.y;
-        const float g = __builtin_amdgcn_exp2f(-(X * X + Y * Y));     // A..D pre-scaled: see write_records
-        const float a = min_f32(q1.z * g, rp.clamp_max_alpha);
+        // alpha * g in one exponential: A..D pre-scaled, q1.z = -log2(alpha) (write_records<true>)
+        const float a = min_f32(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
         T -= w;
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
