@@ -169,7 +169,10 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   constexpr int BATCH = G::BATCH;
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ float4 s_cull[BATCH * 2];
-  __shared__ int32_t s_id[BATCH];
+  // element offsets of the staged splats' gradient rows, one array per output (id * 7, id * 3, id * 2): the
+  // stager multiplies once per splat; a 32-bit v_mul_lo per (patch, splat) commit would be quarter rate
+  constexpr int NOUT = HEUR ? 3 : 2;
+  __shared__ uint32_t s_off[NOUT][BATCH];
 
   const int tile_id = rp.tile_begin + blockIdx.x;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
@@ -197,12 +200,12 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   // which output word this lane commits after the butterfly: value k < 7 -> grad_points[id][k],
   // k < 10 -> grad_feats[id][k - 7], then the two heuristics
   float* tgt = nullptr;
-  unsigned tgt_stride = 0;
+  const uint32_t* tgt_off = s_off[0];      // this lane's row-offset array
   if ((lane & 15) >= 12) {
     const int k = butterfly_slot(lane);
-    if (k < 7) { if (grad_points) { tgt = grad_points + k; tgt_stride = 7; } }
-    else if (k < 10) { if (grad_feats) { tgt = grad_feats + (k - 7); tgt_stride = 3; } }
-    else if (HEUR && k < 12) { if (heuristic) { tgt = heuristic + (k - 10); tgt_stride = 2; } }
+    if (k < 7) { if (grad_points) tgt = grad_points + k; }
+    else if (k < 10) { if (grad_feats) { tgt = grad_feats + (k - 7); tgt_off = s_off[1]; } }
+    else if (HEUR && k < 12) { if (heuristic) { tgt = heuristic + (k - 10); tgt_off = s_off[NOUT - 1]; } }
   }
   const bool b0 = lane & 1, b1 = lane & 2;
 
@@ -221,7 +224,10 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
     if (__syncthreads_and(T <= rp.one_minus_saturate)) break;
     if (stager && begin + t < end) {
       write_records(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
-      s_id[t] = raw.id;
+      const uint32_t id = (uint32_t)raw.id;
+      s_off[0][t] = id * 7u;
+      s_off[1][t] = id * 3u;
+      if (HEUR) s_off[NOUT - 1][t] = id * 2u;
     }
     if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
     if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
@@ -306,8 +312,7 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 #else
           if (tgt) {
 #endif
-            const unsigned id = (unsigned)s_id[r + b];
-            atomic_add_noret(tgt + (size_t)(id * tgt_stride), total);
+            atomic_add_noret(tgt + (size_t)tgt_off[r + b], total);
           }
         }
 
