@@ -170,7 +170,7 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ float4 s_cull[BATCH * 2];
   // element offsets of the staged splats' gradient rows, one array per output (id * 7, id * 3, id * 2): the
-  // stager multiplies once per splat; a 32-bit v_mul_lo per (patch, splat) commit would be quarter rate
+  // stager multiplies once per splat instead of every (patch, splat) commit doing it
   constexpr int NOUT = HEUR ? 3 : 2;
   __shared__ uint32_t s_off[NOUT][BATCH];
 
