@@ -38,13 +38,23 @@ constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2
 // FWD_FORM (forward kernel): A..D are stored pre-scaled by sqrt(log2(e) / 2) and the alpha slot holds
 // -log2(alpha), so that alpha * g = exp2(-(X^2 + Y^2 - log2 alpha)) is two FMAs and one v_exp_f32; the
 // backward needs the true X, Y and g and keeps the plain form.
+// In FWD_FORM the mean is replaced by (cX, cY) = basis * (mean - origin), origin = the tile centre, so that
+// X = fma(px - ox, A, fma(py - oy, B, -cX)): two FMAs per axis instead of two subtractions + MUL + FMA (FMA /
+// MUL issue at 2.5 cycles, ADD / SUB at 3+).  Tile-centre-relative coordinates keep every product below
+// ~16 / sigma, so the rounding of the expanded form stays ~1e-6 in X.
 template <bool FWD_FORM = false>
-__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull) {
+__device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull,
+                                              float origin_x = 0.0f, float origin_y = 0.0f) {
   const float basis_scale = FWD_FORM ? EXP2_BASIS_SCALE : 1.0f;
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
   const float isx = 1.0f / sx, isy = 1.0f / sy;
   const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
-  rec[0] = make_float4(mx, my, A * basis_scale, B * basis_scale);
+  if (FWD_FORM) {
+    const float rx = mx - origin_x, ry = my - origin_y;
+    rec[0] = make_float4((rx * A + ry * B) * basis_scale, (rx * C + ry * D) * basis_scale, A * basis_scale, B * basis_scale);
+  } else {
+    rec[0] = make_float4(mx, my, A, B);
+  }
   rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -log2f(alpha) : alpha, r.f[0]);
   rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
   // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))

@@ -60,6 +60,8 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   const float px = (float)pix_x + 0.5f, py = (float)pix_y + 0.5f;
   const float rcx = (float)patch_x + 4.0f, rcy = (float)patch_y + 4.0f;
   const bool in_bounds = pix_x < rp.width && pix_y < rp.height;
+  const float origin_x = (float)(tile_u * TS) + 0.5f * TS, origin_y = (float)(tile_v * TS) + 0.5f * TS;
+  const float pxr = px - origin_x, pyr = py - origin_y;
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   float T = in_bounds ? 1.0f : 0.0f;     // transmittance = 1 - accumulated weight
@@ -83,7 +85,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       s_vis[t] = 0.0f;
     }
     if (stager && begin + t < end) {
-      write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2]);
+      write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2], origin_x, origin_y);
       if (VIS) s_id[t] = raw.id;
     }
     if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
@@ -118,9 +120,9 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1], n2 = s_rec[(r + nb) * 3 + 2];
 #endif
 
-        const float dx = px - q0.x, dy = py - q0.y;
-        const float X = dx * q0.z + dy * q0.w;
-        const float Y = dx * q1.x + dy * q1.y;
+        // (X, Y) = basis * (pixel - mean), expanded around the tile centre (write_records<true>)
+        const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
+        const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
         // alpha * g in one exponential: A..D pre-scaled, q1.z = -log2(alpha) (write_records<true>)
         const float a = min_f32(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
