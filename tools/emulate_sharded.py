@@ -78,14 +78,18 @@ def main():
   W = args.world
 
   def timed(fn):
+    """Median wall time of one step (each step bracketed by a device synchronisation)."""
     for _ in range(args.warmup):
       fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    times = []
     for _ in range(args.steps):
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
       fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / args.steps * 1e3
+      torch.cuda.synchronize()
+      times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    return times[len(times) // 2]
 
   full = g.clone().requires_grad_(True)
 
