@@ -541,36 +541,6 @@ bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ra
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
 
-// sub-patch edition of the product kernels (four splats per wave instruction): raster_sub.hip
-bool ms_raster_fwd_sub(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
-                       int w, int h, const ms_raster_config* cfg, void* image, void* alpha, int row_begin,
-                       int num_tiles, hipStream_t s);
-bool ms_raster_bwd_sub(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
-                       const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
-                       void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
-
-// MS_RASTER_KERNEL=sub selects the experimental sub-patch kernels of raster_sub.hip (four splats per wave
-// instruction, one per 4x4 sub-patch).  They execute 0.67x the VALU instructions of the default
-// one-splat-per-wave kernels (raster_fast.hip) but commit gradients per (sub-patch, splat): the LDS
-// float atomics that pre-aggregate them cost ~34 LDS cycles per ds_add_f32 and make the backward
-// LDS-bound — config D: forward 0.78 vs 0.74 ms, backward 2.96 vs 2.93 ms — so they are not the default.
-static int raster_kernel_mode() {
-  static const int mode = [] {
-    const char* e = getenv("MS_RASTER_KERNEL");
-    if (e && strcmp(e, "sub") == 0) return 1;
-    if (e && strcmp(e, "pairs") == 0) return 2;
-    if (e && strcmp(e, "patch") == 0) return 3;
-    return 0;
-  }();
-  return mode;
-}
-static bool use_subpatch_kernels() { return raster_kernel_mode() == 1; }
-
-// active-pair compaction backward (raster_pairs.hip)
-bool ms_raster_bwd_pairs(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
-                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
-                         void* gp, void* gf, int row_begin, int num_tiles, hipStream_t s);
-
 static int check_raster_common(const ms_raster_config* cfg, int w, int h, int f, int dtype, int* row_begin,
                                int* row_end, const char* fn) {
   if (!cfg) { set_error("%s: cfg is null", fn); return MS_ERR_BAD_ARG; }
@@ -603,12 +573,8 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending) {
     void* vis = (cfg->compute_visibility && out_visibility) ? out_visibility : nullptr;
-    const bool ok = (use_subpatch_kernels() && !vis)
-        ? ms_raster_fwd_sub(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                            out_alpha, tile_row_begin, num_tiles, s)
-        : ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                             out_alpha, vis, tile_row_begin, num_tiles, s);
-    if (ok) {
+    if (ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
+                           out_alpha, vis, tile_row_begin, num_tiles, s)) {
       MS_CHECK_LAUNCH();
       return 0;
     }
@@ -639,20 +605,9 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
   const int tiles_wide = (image_w + cfg->tile_size - 1) / cfg->tile_size;
   const int num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == MS_F32 && f == 3 && !cfg->antialias && raster_kernel_mode() == 2 && !point_heuristic) {
-    if (ms_raster_bwd_pairs(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
-                            cfg, grad_points7, grad_features, tile_row_begin, num_tiles, s)) {
-      MS_CHECK_LAUNCH();
-      return 0;
-    }
-  }
   if (dtype == MS_F32 && f == 3 && !cfg->antialias) {
-    const bool ok = use_subpatch_kernels()
-        ? ms_raster_bwd_sub(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
-                            cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)
-        : ms_raster_bwd_fast(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
-                             cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s);
-    if (ok) {
+    if (ms_raster_bwd_fast(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h,
+                           cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)) {
       MS_CHECK_LAUNCH();
       return 0;
     }

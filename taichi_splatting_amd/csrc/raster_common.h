@@ -1,4 +1,4 @@
-// raster_common.h — pieces shared by the product raster kernels (raster_fast.hip, raster_sub.hip):
+// raster_common.h — pieces shared by the raster kernels (raster_fast.hip, and the float commit of raster.hip):
 // kernel parameters, the two-deep gather pipeline's raw record, the LDS blend / cull records, the
 // conservative rectangle-vs-contribution-ellipse test and the wave64 halving butterfly.
 #pragma once
@@ -67,7 +67,7 @@ __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshol
 }
 
 // does the splat's contribution region possibly touch the rectangle of pixel centres with centre
-// (rcx, rcy) and half size h (3.5 for an 8x8 patch, 1.5 for a 4x4 sub-patch)?  Conservative: false
+// (rcx, rcy) and half size h (3.5 for an 8x8 patch)?  Conservative: false
 // only if provably no pixel of the rectangle passes alpha * g > threshold.
 __device__ __forceinline__ bool rect_hit(const float4 c0, const float4 c1, float rcx, float rcy, float h) {
   const float dx = rcx - c0.x, dy = rcy - c0.y;   // rectangle centre relative to the mean

@@ -262,49 +262,3 @@ def test_f32_antialias_matches_f64(tile_size, n, size, scale, alpha):
     rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
     assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
     assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
-
-
-@pytest.mark.parametrize('mode,heur,tile_size,n,size,scale', [
-    ('sub', True, 16, 60000, (500, 300), 1.2),
-    ('pairs', False, 16, 60000, (500, 300), 1.2),
-    ('pairs', False, 8, 20000, (333, 200), 3.0),
-    ('pairs', False, 32, 120000, (640, 480), 0.7)])
-def test_alternative_kernels_match_default_kernels(mode, heur, tile_size, n, size, scale):
-  # raster_sub.hip (MS_RASTER_KERNEL=sub) / raster_pairs.hip (=pairs) against the patch kernels of
-  # raster_fast.hip (=patch), each in a fresh process
-  import subprocess, sys, textwrap, tempfile, os
-  code = textwrap.dedent('''
-    import os, sys, torch
-    sys.path.insert(0, os.getcwd())
-    from taichi_splatting_amd import RasterConfig, rasterize_with_tiles, map_to_tiles
-    from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
-    from taichi_splatting_amd.testing import random_2d_gaussians
-    heur, tile_size, n, w, h, scale = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7])
-    torch.manual_seed(0)
-    size = (w, h)
-    cfg = RasterConfig(tile_size=tile_size, pixel_stride=(1, 1) if tile_size == 8 else (2, 2), compute_point_heuristic=bool(heur))
-    g = random_2d_gaussians(n, size, scale_factor=scale).to('cuda:0')
-    p = project_gaussians2d(g).requires_grad_(True); f = g.feature.clone().requires_grad_(True)
-    o2p, ranges = map_to_tiles(p, g.depths, size, cfg)
-    out = rasterize_with_tiles(p, f, o2p, ranges.view(-1, 2), size, cfg)
-    torch.manual_seed(1)
-    (out.image * torch.randn_like(out.image)).sum().backward()
-    res = dict(image=out.image.detach().cpu(), gp=p.grad.cpu(), gf=f.grad.cpu())
-    if heur: res['h'] = out.point_heuristic.cpu()
-    torch.save(res, sys.argv[1])
-  ''')
-  with tempfile.TemporaryDirectory() as d:
-    res = {}
-    for m in ('patch', mode):
-      path = os.path.join(d, m + '.pt')
-      env = dict(os.environ, MS_RASTER_KERNEL=m)
-      subprocess.run([sys.executable, '-c', code, path, str(int(heur)), str(tile_size), str(n), str(size[0]), str(size[1]), str(scale)],
-                     check=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
-      res[m] = torch.load(path)
-  a, b = res['patch'], res[mode]
-  assert torch.allclose(a['image'], b['image'], atol=2e-6)
-  assert a['gp'].abs().sum() > 0
-  for k in a:
-    if k == 'image': continue
-    scale_ = a[k].abs().max().item()
-    assert (a[k] - b[k]).abs().max() < 1e-4 * scale_ + 1e-6, k
