@@ -19,15 +19,9 @@
 #ifndef MS_ABLATE
 #define MS_ABLATE 0
 #endif
-// hit-loop flavour (measured on config D): the forward blend is short, so a software prefetch of the
-// next record pays (0.87 vs 0.95 ms); the backward body is long enough for the other waves to hide
-// the LDS latency and the leaner scalar walk wins (2.93 vs 2.99 ms)
-#ifndef MS_LEAN_FWD
-#define MS_LEAN_FWD 0
-#endif
-#ifndef MS_LEAN_BWD
-#define MS_LEAN_BWD 1
-#endif
+// Hit-loop flavour (both measured on config D): the forward walks the hit mask with the record of the next hit
+// requested one iteration ahead; the backward body is long enough for the other waves of the SIMD to hide the
+// LDS latency and uses the leaner walk (one s_ff1 + one bit clear + one v_readlane per hit).
 
 namespace ms {
 
@@ -97,17 +91,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       bool hit = false;
       if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
       unsigned long long m = __ballot(hit);
-#if MS_LEAN_FWD
-      // lean scalar walk: one s_ff1 + one bit clear + one v_readlane per hit; LDS latency is hidden
-      // by the other waves of the SIMD rather than by a software prefetch
-      const int rec_index = j * 3;
-      while (m) {
-        const int b = __builtin_ctzll(m);
-        m &= ~(1ull << b);
-        const int ri = __builtin_amdgcn_readlane(rec_index, b);
-        const float4 q0 = s_rec[ri + 0], q1 = s_rec[ri + 1], q2 = s_rec[ri + 2];
-        const bool more = true;
-#else
       if (m == 0) continue;
       int b = __builtin_ctzll(m);
       m &= m - 1;
@@ -118,7 +101,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         m &= m - 1;
         // prefetch the next hit's record (re-reads the current one on the last iteration)
         const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1], n2 = s_rec[(r + nb) * 3 + 2];
-#endif
 
         // (X, Y) = basis * (pixel - mean), expanded around the tile centre (write_records<true>)
         const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
@@ -135,12 +117,8 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
           }
         }
 
-#if !MS_LEAN_FWD
         if (!more) break;
         b = nb; q0 = n0; q1 = n1; q2 = n2;
-#else
-        (void)more;
-#endif
       }
     }
   }
@@ -243,24 +221,12 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       bool hit = false;
       if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
       unsigned long long m = __ballot(hit);
-#if MS_LEAN_BWD
       const int rec_index = j * 3;
       while (m) {
         const int b = __builtin_ctzll(m);
         m &= ~(1ull << b);
         const int ri = __builtin_amdgcn_readlane(rec_index, b);
         const float4 q0 = s_rec[ri + 0], q1 = s_rec[ri + 1], q2 = s_rec[ri + 2];
-#else
-      if (m == 0) continue;
-      int b = __builtin_ctzll(m);
-      m &= m - 1;
-      float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1], q2 = s_rec[(r + b) * 3 + 2];
-      while (true) {
-        const bool more = m != 0;
-        const int nb = more ? __builtin_ctzll(m) : b;
-        m &= m - 1;
-        const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1], n2 = s_rec[(r + nb) * 3 + 2];
-#endif
 
         const float A = q0.z, B = q0.w, C = q1.x, D = q1.y, alpha_pt = q1.z;
         const float f0 = q1.w, f1 = q2.x, f2 = q2.y, isx = q2.z, isy = q2.w;
@@ -318,10 +284,6 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
           }
         }
 
-#if !MS_LEAN_BWD
-        if (!more) break;
-        b = nb; q0 = n0; q1 = n1; q2 = n2;
-#endif
       }
     }
   }
