@@ -186,6 +186,29 @@ int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile
                   void* grad_points7, void* grad_features, void* point_heuristic,
                   int tile_row_begin, int tile_row_end, int dtype, void* stream);
 
+/* Product-path backward (float32, F = 3, plain pdf, alpha blending) in two steps — same semantics as
+ * ms_raster_bwd / rasterizer/backward.py:97-224, different organisation (csrc/raster_bwd_scan.hip):
+ *
+ * ms_raster_bwd_moments ACCUMULATES, per point, one 64-byte row of MS_MOMENT_ROW floats into `moments`
+ * (V, MS_MOMENT_ROW), pre-zeroed by the caller, 64-byte aligned:
+ *   [0..5]  sum over contributing pixels of q * (1, X', Y', X'^2, X'Y', Y'^2),  q = alpha_pt g dL/dalpha
+ *           (backward.py:171-188), (X', Y') = sqrt(log2(e)/2) * the pixel in the splat's normalised frame
+ *           (generic.py:311-317)
+ *   [6..8]  dL/dfeature = sum w G_c (backward.py:197)
+ *   [9..10] with cfg->compute_point_heuristic: sum (dL/dalpha)^2 and sqrt-scaled sum |dL/dmean|_1
+ *           (backward.py:190-194)
+ * Every geometric gradient of gaussian_pdf_with_grad (generic.py:321-336) is a per-splat linear map of these
+ * sums; ms_raster_moments_finalize applies it once per point and STORES grad_points7 (V,7), grad_features
+ * (V,3) and point_heuristic (V,2) (each may be NULL). */
+#define MS_MOMENT_ROW 16
+int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
+                          const int32_t* overlap_to_point, const void* image, const void* grad_image,
+                          int image_w, int image_h, const ms_raster_config* cfg, float* moments,
+                          int tile_row_begin, int tile_row_end, void* stream);
+int ms_raster_moments_finalize(const void* points7, const float* moments, int64_t n,
+                               float* grad_points7, float* grad_features, float* point_heuristic,
+                               void* stream);
+
 /* ---- optimiser step ------------------------------------------------------------
  * Moment update of the fractional (visibility-weighted) Adam (kind 0, optim/fractional_adam.py:8-86)
  * and LaProp (kind 1, optim/fractional_laprop.py:8-86) for the m_count visible points listed in

@@ -20,6 +20,7 @@ CSRC_DIR = PACKAGE_DIR / 'csrc'
 LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB', PACKAGE_DIR / 'libmi355_splat.so'))   # env override: profiling builds
 
 MS_F32, MS_F64 = 0, 1
+MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -65,6 +66,8 @@ SIGNATURES = {
   'ms_strip_return_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
   'ms_fractional_update': (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
+  'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_int, c_void_p]),
+  'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
 }
 

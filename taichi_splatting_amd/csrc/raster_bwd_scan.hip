@@ -1,0 +1,392 @@
+// raster_bwd_scan.hip — product-path raster backward (float32, RGB, plain gaussian pdf, alpha blending):
+// semantics of rasterizer/backward.py:97-224, organised for wave64 so that NO per-splat cross-lane gradient
+// reduction exists at all.
+//
+// The reference (and round 1 of this library) maps one thread to one pixel, walks the tile's splats in depth
+// order and, for every splat, sums the 7 + 3 (+2) per-pixel gradient terms over the pixels of a warp / wave
+// (backward.py:200-224; taichi_lib/concurrent.py:11-23,69-86).  With small splats only a few of the 64 pixels of
+// a wave contribute to a given splat, so most lanes compute and reduce zeros.
+//
+// Here the roles are transposed:
+//
+//   * one workgroup per tile, one wave per 8x8 pixel patch = four 4x4 SUB-PATCHES;
+//   * per staged batch (<= 256 splats, LDS) every wave tests the splats against each of its sub-patches (one
+//     splat per lane, same conservative oriented-box test as the tile mapper, grid_query.py:30-43) and compacts
+//     the hits into per-sub-patch lists (ballot + mbcnt, order preserving => still depth sorted);
+//   * a sub-patch list is consumed in chunks of 64 hits with ONE SPLAT PER LANE.  The 16 pixels of the
+//     sub-patch are visited one after the other; the pixel (its coordinates, transmittance T, dL/dC and the
+//     colour still to come <R, G>) is wave-uniform and lives in SGPRs (v_readlane from state registers whose lane
+//     p holds pixel p).  The front-to-back recurrence over the 64 splats of the chunk is two DPP prefix scans:
+//         T_k  = T_in * prod_{j<k} (1 - a_j)            (multiplicative, exclusive: wave_shr:1 + 6 v_mul_f32_dpp)
+//         S_k  = sum_{j<=k} w_j <f_j, G>                 (additive, inclusive: 6 v_add_f32_dpp)
+//     so each lane knows the T and <R, G> its splat sees at this pixel, evaluates d(alpha) and accumulates ITS
+//     splat's gradient in ITS OWN registers over the 16 pixels — no butterfly, no atomics in the loop;
+//   * what a lane accumulates are the six moments  sum q, q X, q Y, q X^2, q X Y, q Y^2  (q = alpha g dL/dalpha,
+//     (X, Y) = pixel in the splat's normalised frame) plus sum w G_c: every geometric gradient of
+//     generic.py:321-336 is a per-splat LINEAR map of these sums, applied once per gaussian by
+//     raster_moments_finalize_kernel (or by the fused projection/SH backward) instead of once per pixel;
+//   * a chunk ends with one ds_add_f32 per moment into the tile's accumulators (lanes = distinct splats, so no
+//     same-address serialisation), and a batch ends with ONE 64-byte, line-aligned row of global float atomics
+//     per (tile, splat): 16 lanes commit the 16 floats of moments[id] in one instruction.
+//
+// VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~56 instructions / (lanes filled) ~= 18 wave
+// instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
+#include "raster_common.h"
+
+namespace ms {
+
+constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
+constexpr int SCAN_BATCH = 256;               // splats staged per batch (list entries are uint8)
+
+// Inclusive prefix product / sum over the 64 lanes: row_shr:1,2,4,8 build the 16-lane row prefixes, row_bcast:15
+// (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row totals — six DPP instructions.  Lanes without a source
+// (and rows masked off) keep their value, which is the identity of the scan: exactly what v_*_dpp without
+// bound_ctrl does when it writes in place.  Written in assembly because LLVM's DPP combiner does not treat
+// 1.0f / 0.0f as identities of v_mul_f32 / v_add_f32 (it emits v_mov_b32 + v_mov_b32_dpp + v_mul_f32 per step);
+// "s_nop 1" = the two wait states a DPP read needs after the VALU write of its source.
+#define MS_SCAN_ASM(OP)                                                                           \
+  asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                    \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                    \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                    \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                    \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"                      \
+      : "+v"(v))
+__device__ __forceinline__ float wave_scan_mul(float v) { MS_SCAN_ASM("v_mul_f32_dpp"); return v; }
+__device__ __forceinline__ float wave_scan_add(float v) { MS_SCAN_ASM("v_add_f32_dpp"); return v; }
+#undef MS_SCAN_ASM
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// state[lane] = value for two state registers at once: v_writelane_b32 with wave-uniform (SGPR) value and lane.
+// gfx9 VALU instructions read at most one SGPR, so the lane select goes through M0 (which nothing else in this
+// kernel uses: gfx9 LDS instructions do not need it).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void writelane2_f(float& s0, float v0, float& s1, float v1, int lane) {
+  asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+               : "+v"(s0), "+v"(s1) : "s"(v0), "s"(v1), "s"(lane) : "m0");
+}
+#pragma clang diagnostic pop
+
+typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+
+// 48-byte LDS record of a staged splat:
+//   [mx my A' B'] [C' D' -log2(alpha) f0] [f1 f2 half2(ex, ey) R]
+// A'..D' = basis * s, s = sqrt(log2(e) / 2), so alpha g = exp2(-(X'^2 + Y'^2 - log2 alpha)).  Cull data (same
+// contribution region alpha g > alpha_threshold as write_records()): (ex, ey) = axis-aligned half extents of the
+// ellipse, rounded UP to fp16 (+inf beyond the fp16 range: such a splat passes the rectangle-axis test, the
+// ellipse-axis tests still apply); R = s * cutoff radius, i.e. |X'| - (|A'| + |B'|) h <= R on the ellipse axes.
+__device__ __forceinline__ void write_scan_record(const Raw& r, float alpha_threshold, float4* rec) {
+  const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
+  const float isx = 1.0f / sx, isy = 1.0f / sy;
+  const float s = EXP2_BASIS_SCALE;
+  rec[0] = make_float4(mx, my, ax * isx * s, ay * isx * s);
+  rec[1] = make_float4(-ay * isy * s, ax * isy * s, -log2f(alpha), r.f[0]);
+  const float gs = sqrtf(2.0f * logf(alpha / alpha_threshold)) * 1.001f;     // NaN below the threshold: culled
+  const float v1x = ax * sx * gs, v1y = ay * sx * gs, v2x = -ay * sy * gs, v2y = ax * sy * gs;
+  float ex = (sqrtf(v1x * v1x + v2x * v2x) + 0.01f) * 1.002f, ey = (sqrtf(v1y * v1y + v2y * v2y) + 0.01f) * 1.002f;
+  ex = ex > 6.0e4f ? __builtin_inff() : ex;      // cvt_pkrtz rounds toward zero: pre-inflated by 2^-9
+  ey = ey > 6.0e4f ? __builtin_inff() : ey;
+  const half2_t e = __builtin_amdgcn_cvt_pkrtz(ex, ey);
+  rec[2] = make_float4(r.f[1], r.f[2], __builtin_bit_cast(float, e), gs * s * 1.002f);
+}
+
+// conservative test: can the contribution region touch the rectangle of pixel centres with centre (rcx, rcy)
+// and half size h?  (rect_hit() of raster_common.h on the packed record)
+__device__ __forceinline__ bool scan_rect_hit(const float4 q0, const float4 q1, const float4 q2, float rcx, float rcy,
+                                              float h) {
+  const half2_t e = __builtin_bit_cast(half2_t, q2.z);
+  const float dx = rcx - q0.x, dy = rcy - q0.y;
+  bool hit = (fabsf(dx) <= (float)e[0] + h) && (fabsf(dy) <= (float)e[1] + h);
+  const float p1 = q0.z * dx + q0.w * dy, e1 = (fabsf(q0.z) + fabsf(q0.w)) * h;
+  const float p2 = q1.x * dx + q1.y * dy, e2 = (fabsf(q1.x) + fabsf(q1.y)) * h;
+  return hit && (fabsf(p1) - e1 <= q2.w) && (fabsf(p2) - e2 <= q2.w);
+}
+
+template <int TS, bool HEUR>
+__global__ void __launch_bounds__(TS * TS)
+raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
+                       const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
+                       const float* __restrict__ image, const float* __restrict__ grad_image,
+                       FastParams rp, float* __restrict__ moments) {
+  constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
+  constexpr int BATCH = SCAN_BATCH;
+  constexpr int NACC = HEUR ? 11 : 9;
+  constexpr bool PIPELINED = THREADS >= BATCH;   // one staged splat per thread, gathered one batch ahead
+  // 12 + 18 (22 with heuristics) + 2 + 4 KB at tile 16: four workgroups per CU
+  __shared__ float4 s_rec[BATCH * 3];
+  __shared__ float s_acc[2][BATCH][NACC];        // odd row length: zeroing, ds_add and the transposed commit stay spread over the banks
+  __shared__ int32_t s_id[2][BATCH];
+  __shared__ uint8_t s_list[WAVES][4][BATCH];
+
+  const int tile_id = rp.tile_begin + blockIdx.x;
+  const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
+  const int t = threadIdx.x, wave = t >> 6, lane = lane_id();
+  const int patch_x = tile_u * TS + (wave % WAVES_WIDE) * 8;
+  const int patch_y = tile_v * TS + (wave / WAVES_WIDE) * 8;
+
+  // pixel state: lane p = 16 * sub + 4 * y + x holds pixel (x, y) of sub-patch `sub` (sub-patches 2 x 2)
+  const int sub = lane >> 4;
+  const int pix_x = patch_x + (sub & 1) * 4 + (lane & 3), pix_y = patch_y + (sub >> 1) * 4 + ((lane >> 2) & 3);
+  float G0s = 0.f, G1s = 0.f, G2s = 0.f, RGs = 0.f, Ts = 0.f;     // T = 0: out-of-image pixels never blend
+  if (pix_x < rp.width && pix_y < rp.height) {
+    const int64_t p = (int64_t)pix_y * rp.width + pix_x;
+    G0s = grad_image[p * 3 + 0]; G1s = grad_image[p * 3 + 1]; G2s = grad_image[p * 3 + 2];
+    RGs = image[p * 3 + 0] * G0s + image[p * 3 + 1] * G1s + image[p * 3 + 2] * G2s;   // <R, G>, R = forward image
+    Ts = 1.0f;
+  }
+  const float oms = rp.one_minus_saturate;
+  const uint32_t oms_bits = __float_as_uint(oms);     // T >= 0: the float order is the order of the bit patterns
+
+  const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
+
+  Raw raw;
+  int next_id = 0;
+  if (PIPELINED) {
+    if (t < BATCH && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
+    if (t < BATCH && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
+  }
+
+  // transposed commit of a finished batch: 16 consecutive lanes add the 16 floats of one splat's moments row
+  auto commit = [&](int buf, int n) {
+    for (int i = t; i < n * MOMENT_ROW; i += THREADS) {
+      const int slot = i >> 4, k = i & 15;
+      if (k < NACC) {
+        const float v = s_acc[buf][slot][k];
+        if (v != 0.0f) atomic_add_noret(moments + (size_t)(uint32_t)s_id[buf][slot] * MOMENT_ROW + k, v);
+      }
+    }
+  };
+
+  int b = 0, prev_count = 0;
+  for (int begin = start; begin < end; begin += BATCH, ++b) {
+    const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
+    const int buf = b & 1;
+    // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
+    // (backward.py:116)
+    if (__syncthreads_and(__float_as_uint(Ts) <= oms_bits)) break;
+
+    if (PIPELINED) {
+      if (t < count) {
+        write_scan_record(raw, rp.alpha_threshold, &s_rec[t * 3]);
+        s_id[buf][t] = raw.id;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s_acc[buf][t][k] = 0.0f;
+      }
+      if (t < BATCH && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
+      if (t < BATCH && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
+    } else {
+      for (int s = t; s < count; s += THREADS) {
+        const Raw r = load_raw(points, feats, o2p[begin + s]);
+        write_scan_record(r, rp.alpha_threshold, &s_rec[s * 3]);
+        s_id[buf][s] = r.id;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) s_acc[buf][s][k] = 0.0f;
+      }
+    }
+    __syncthreads();
+
+    if (b > 0) commit(buf ^ 1, prev_count);
+    prev_count = count;
+
+    // wave-wide early out (backward.py:142)
+    if (__ballot(__float_as_uint(Ts) > oms_bits) == 0) continue;
+
+    // ---- cull: per sub-patch hit lists (depth order preserved) -----------------------------------------------
+    int cnt[4] = {0, 0, 0, 0};
+    for (int r = 0; r < count; r += 64) {
+      const int j = r + lane;
+      const bool in = j < count;
+      const float4 q0 = s_rec[j * 3 + 0], q1 = s_rec[j * 3 + 1], q2 = s_rec[j * 3 + 2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
+        const bool hit = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
+        const unsigned long long m = __ballot(hit);
+        const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (hit) s_list[wave][q][pos] = (uint8_t)j;
+        cnt[q] += __builtin_popcountll(m);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- blend: lane = splat, 16 pixel steps per chunk --------------------------------------------------------
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
+      if (n == 0) continue;
+      const unsigned long long alive = __ballot(__float_as_uint(Ts) > oms_bits);
+      if (((alive >> (16 * q)) & 0xffffull) == 0) continue;
+      const int pbase = q * 16;
+      const float fx = (float)(patch_x + (q & 1) * 4) + 0.5f, fy = (float)(patch_y + (q >> 1) * 4) + 0.5f;
+
+#pragma unroll 1
+      for (int c0 = 0; c0 < n; c0 += 64) {
+        const bool valid = c0 + lane < n;
+        const int idx = valid ? (int)s_list[wave][q][c0 + lane] : 0;
+        const float4 q0 = s_rec[idx * 3 + 0], q1 = s_rec[idx * 3 + 1], q2 = s_rec[idx * 3 + 2];
+        const float A = q0.z, B = q0.w, C = q1.x, D = q1.y;
+        const float nl2a = valid ? q1.z : __builtin_inff();       // idle lanes: alpha g = exp2(-inf) = 0
+        const float f0 = q1.w, f1 = q2.x, f2 = q2.y;
+        const float dx0 = fx - q0.x, dy0 = fy - q0.y;             // first pixel centre of the sub-patch - mean
+        const float X00 = A * dx0 + B * dy0, Y00 = C * dx0 + D * dy0;
+        // (X', Y') at the first pixel of each of the four pixel rows; a step adds x * (A, C)
+        const float Xr[4] = {X00, X00 + B, __builtin_fmaf(B, 2.0f, X00), __builtin_fmaf(B, 3.0f, X00)};
+        const float Yr[4] = {Y00, Y00 + D, __builtin_fmaf(D, 2.0f, Y00), __builtin_fmaf(D, 3.0f, Y00)};
+
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        float h0 = 0.f, h1 = 0.f;
+
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int p = pbase + i;
+          const float Tin = readlane_f(Ts, p);
+          if (__float_as_uint(Tin) > oms_bits) {                  // saturated / out-of-image pixel: skipped
+            const float cx = (float)(i & 3);
+            const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
+            const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
+            const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X, X, __builtin_fmaf(Y, Y, nl2a)));
+            const bool contrib = a_raw > rp.alpha_threshold;
+            const float a_clamped = min_f32(a_raw, rp.clamp_max_alpha);
+            const float a = contrib ? a_clamped : 0.0f;
+            const float om = 1.0f - a;
+            // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
+            const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
+            const float w = Tk > oms ? a * Tk : 0.0f;                             // saturation skip (backward.py:154)
+            const float g0 = readlane_f(G0s, p), g1 = readlane_f(G1s, p), g2 = readlane_f(G2s, p);
+            const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
+            // <R, G> after this splat: R -= f w  (backward.py:171-174)
+            const float RGk = readlane_f(RGs, p) - wave_scan_add(w * fG);
+            // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
+            const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
+            // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha)
+            const float q = w != 0.0f ? ag * a_raw : 0.0f;
+            const float qX = q * X, qY = q * Y;
+            m0 += q; m1 += qX; m2 += qY;
+            m3 = __builtin_fmaf(qX, X, m3); m4 = __builtin_fmaf(qX, Y, m4); m5 = __builtin_fmaf(qY, Y, m5);
+            a0 = __builtin_fmaf(w, g0, a0); a1 = __builtin_fmaf(w, g1, a1); a2 = __builtin_fmaf(w, g2, a2);
+            if (HEUR) {                                           // backward.py:190-194
+              const float agm = w != 0.0f ? ag : 0.0f;
+              h0 = __builtin_fmaf(agm, agm, h0);
+              h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+            }
+            writelane2_f(Ts, readlane_f(Tk * om, 63), RGs, readlane_f(RGk, 63), p);
+          }
+        }
+
+        if (valid) {
+          float* acc = &s_acc[buf][idx][0];
+          const float v[11] = {m0, m1, m2, m3, m4, m5, a0, a1, a2, h0, h1};
+#pragma unroll
+          for (int k = 0; k < NACC; ++k)
+            __hip_atomic_fetch_add(acc + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+
+  __syncthreads();
+  if (b > 0) commit((b - 1) & 1, prev_count);
+}
+
+// Moments -> gradients of the packed 2D gaussian and its colour (one thread per point; plain stores).
+// With (X, Y) = M (pixel - mean), M = [[A, B], [C, D]] = diag(1/sx, 1/sy) [axis; perp(axis)] and the sums
+// S = sum q, Sx = sum q X, ..., Syy = sum q Y^2 over all contributing pixels (q = alpha g dL/dalpha):
+//   d mean  = M^T (Sx, Sy)                                  d sigma = (Sxx / sx, Syy / sy)
+//   d axis  = sum q (X/sx (-d) + Y/sy perp(d)),  d = M^-1 (X, Y)     d alpha = S / alpha      (generic.py:321-336)
+// The kernel stores the moments of (X', Y') = s (X, Y), s = sqrt(log2(e) / 2).
+template <bool HEUR>
+__global__ void __launch_bounds__(256)
+raster_moments_finalize_kernel(const float* __restrict__ points, const float* __restrict__ moments, int64_t n,
+                               float* __restrict__ grad_points, float* __restrict__ grad_feats,
+                               float* __restrict__ heuristic) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4* row = reinterpret_cast<const float4*>(moments + i * MOMENT_ROW);
+  const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+  if (grad_points) {
+    const float* g = points + i * 7;
+    const float ax = g[2], ay = g[3], sx = g[4], sy = g[5], alpha = g[6];
+    const float isx = 1.0f / sx, isy = 1.0f / sy;
+    const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
+    constexpr float IS = 1.0f / EXP2_BASIS_SCALE, IS2 = IS * IS;
+    const float S = r0.x, Sx = r0.y * IS, Sy = r0.z * IS, Sxx = r0.w * IS2, Sxy = r1.x * IS2, Syy = r1.y * IS2;
+    const float det = A * D - B * C;
+    const float idet = det != 0.0f ? 1.0f / det : 0.0f;
+    float* o = grad_points + i * 7;
+    o[0] = Sx * A + Sy * C;
+    o[1] = Sx * B + Sy * D;
+    o[2] = -(isx * (D * Sxx - B * Sxy) + isy * (A * Syy - C * Sxy)) * idet;
+    o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
+    o[4] = isx * Sxx;
+    o[5] = isy * Syy;
+    o[6] = S / alpha;
+  }
+  if (HEUR && heuristic) {                       // backward.py:190-194: sum (alpha d_alpha)^2, sum |d mean|_1
+    const float alpha = points[i * 7 + 6];
+    constexpr float IS2 = 1.0f / (EXP2_BASIS_SCALE * EXP2_BASIS_SCALE);
+    heuristic[i * 2 + 0] = alpha * alpha * r2.y;
+    heuristic[i * 2 + 1] = r2.z * IS2;
+  }
+  if (grad_feats) {
+    grad_feats[i * 3 + 0] = r1.z; grad_feats[i * 3 + 1] = r1.w; grad_feats[i * 3 + 2] = r2.x;
+  }
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
+                                     const int32_t* overlap_to_point, const void* image, const void* grad_image,
+                                     int image_w, int image_h, const ms_raster_config* cfg, float* moments,
+                                     int tile_row_begin, int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments, "null pointer");
+  MS_CHECK_ARG(image_w > 0 && image_h > 0, "bad image size");
+  MS_CHECK_ARG(cfg->use_alpha_blending, "backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)");
+  if (cfg->antialias) { set_error("ms_raster_bwd_moments: antialiased pdf is served by ms_raster_bwd"); return MS_ERR_UNSUPPORTED; }
+  const int ts = cfg->tile_size;
+  if (ts != 8 && ts != 16 && ts != 32) { set_error("ms_raster_bwd_moments: tile_size must be 8, 16 or 32 (got %d)", ts); return MS_ERR_UNSUPPORTED; }
+  const int tiles_high = (image_h + ts - 1) / ts, tiles_wide = (image_w + ts - 1) / ts;
+  if (tile_row_begin < 0) tile_row_begin = 0;
+  if (tile_row_end > tiles_high) tile_row_end = tiles_high;
+  if (tile_row_end <= tile_row_begin) return 0;
+
+  FastParams rp;
+  rp.width = image_w; rp.height = image_h; rp.tiles_wide = tiles_wide; rp.tile_begin = tile_row_begin * tiles_wide;
+  rp.clamp_max_alpha = (float)cfg->clamp_max_alpha;
+  rp.alpha_threshold = (float)cfg->alpha_threshold;
+  rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
+  const dim3 grid((unsigned)((tile_row_end - tile_row_begin) * tiles_wide));
+  hipStream_t s = (hipStream_t)stream;
+#define MS_GO(TS, HEUR) raster_bwd_scan_kernel<TS, HEUR><<<grid, dim3(TS * TS), 0, s>>>(                       \
+      (const float*)points7, (const float*)features, tile_ranges, overlap_to_point, (const float*)image,      \
+      (const float*)grad_image, rp, moments)
+  const bool hf = cfg->compute_point_heuristic;
+  switch (ts) {
+    case 8: if (hf) MS_GO(8, true); else MS_GO(8, false); break;
+    case 16: if (hf) MS_GO(16, true); else MS_GO(16, false); break;
+    default: if (hf) MS_GO(32, true); else MS_GO(32, false); break;
+  }
+#undef MS_GO
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int64_t n,
+                                          float* grad_points7, float* grad_features, float* point_heuristic,
+                                          void* stream) {
+  MS_CHECK_ARG(n >= 0, "negative size");
+  if (n == 0) return 0;
+  MS_CHECK_ARG(points7 && moments, "null pointer");
+  if (!grad_points7 && !grad_features && !point_heuristic) return 0;
+  const dim3 grid((unsigned)div_up(n, 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (point_heuristic) raster_moments_finalize_kernel<true><<<grid, 256, 0, s>>>((const float*)points7, moments, n, grad_points7, grad_features, point_heuristic);
+  else raster_moments_finalize_kernel<false><<<grid, 256, 0, s>>>((const float*)points7, moments, n, grad_points7, grad_features, nullptr);
+  MS_CHECK_LAUNCH();
+  return 0;
+}

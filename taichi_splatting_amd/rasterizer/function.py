@@ -5,6 +5,7 @@ autograd glue :28-97), launching the gfx950 kernels of csrc/raster.hip through t
 from __future__ import annotations
 
 from dataclasses import replace
+import os
 from numbers import Integral
 from typing import NamedTuple, Optional, Tuple
 
@@ -22,6 +23,13 @@ RasterOut = NamedTuple('RasterOut', [
 ])
 
 MAX_KERNEL_FEATURES = 4   # csrc/raster.hip instantiates F = 1..4; wider features are chunked
+
+
+def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
+  """Product path (float32 RGB, plain pdf): csrc/raster_bwd_scan.hip.  ``MS_RASTER_BWD=patch`` selects the
+  pixel-per-lane kernels of raster_fast.hip instead (A/B measurements only)."""
+  return (dtype == torch.float32 and f == 3 and not config.antialias
+          and os.environ.get('MS_RASTER_BWD', 'scan') != 'patch')
 
 
 def _tile_rows(config: RasterConfig, image_size, tile_rows):
@@ -132,11 +140,13 @@ class _RasterFunction(torch.autograd.Function):
     n, f = features.shape
     need_points, need_features = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
 
-    grad_gaussians = torch.zeros_like(gaussians) if need_points else None
-    grad_features = torch.zeros_like(features) if need_features else None
     heuristic = ctx.point_heuristic if config.compute_point_heuristic else None
     if not (need_points or need_features or heuristic is not None):
       return None, None, None, None, None, None, None, None
+    moments_path = _use_moments_backward(config, gaussians.dtype, f) and image.shape[0] > 0 and n > 0
+    alloc = torch.empty_like if moments_path else torch.zeros_like   # the finalize pass stores, the others accumulate
+    grad_gaussians = alloc(gaussians) if need_points else None
+    grad_features = alloc(features) if need_features else None
 
     grad_image = grad_image.contiguous()
     if image.shape[0] == 0:
@@ -146,7 +156,16 @@ class _RasterFunction(torch.autograd.Function):
     dtype_code = _lib.dtype_code(gaussians.dtype)
     cfg_c = _lib.raster_config_c(config)
 
-    if f <= MAX_KERNEL_FEATURES:
+    if moments_path:
+      moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.float32, device=gaussians.device)
+      _lib.check(lib.ms_raster_bwd_moments(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
+                                           _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
+                                           grad_image.data_ptr() - row_bytes * f, w, h, cfg_c, moments.data_ptr(),
+                                           ctx.rows[0], ctx.rows[1], stream), "rasterize backward")
+      _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), n, _lib.ptr(grad_gaussians),
+                                                _lib.ptr(grad_features), _lib.ptr(heuristic), stream),
+                 "rasterize backward (moments -> gradients)")
+    elif f <= MAX_KERNEL_FEATURES:
       _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                    _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
                                    grad_image.data_ptr() - row_bytes * f, w, h, f, cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(grad_features),
