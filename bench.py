@@ -6,9 +6,15 @@
 A step = one full frame: project -> SH colour -> tile map (count/scan/emit/sort/ranges) -> raster
 forward -> loss = image.sum() -> raster backward -> SH backward -> projection backward, on inputs
 already resident in HBM.  Default workload = BASELINE.json configs[3] ("config D": 6M gaussians,
-2048x2048, SH degree 3, tile 16), the configuration the metric is quoted on.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the SAME frame is sharded by screen-tile strips with the
-per-gaussian 2D-boundary gradients all-reduced over RCCL -> "scaling": "strong".
+2048x2048, SH degree 3, tile 16), the configuration the metric is quoted on.
+
+N > 1: one rank per GPU over RCCL, either launched by ``torch.distributed.run`` (RANK / WORLD_SIZE in the
+environment) or, when ``--gpus N`` is given without that environment, by this script re-executing itself under
+``torch.distributed.run`` on 127.0.0.1.  The SAME frame is rendered by the N ranks ("scaling": "strong") in both
+decompositions of taichi_splatting_amd/distributed.py, each timed for K steps: ``strips`` (north_star: gaussians
+replicated, tile-row strips, all-reduce of the 2D-boundary gradients) and ``sharded`` (gaussians sharded by
+index, all-to-all of projected splats and of their gradients).  ``value`` is the faster of the two, named in
+``config.parallelism``; both are in ``modes`` with per-rank times and the bytes each rank exchanges per step.
 
 Prints ONE JSON line on rank 0 (metric, roofline of the dominant kernel, CPU-oracle baseline).
 """
@@ -31,8 +37,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def parse_args():
   p = argparse.ArgumentParser()
   p.add_argument('--gpus', type=int, default=1)
-  p.add_argument('--steps', type=int, default=20)
-  p.add_argument('--warmup', type=int, default=3)
+  p.add_argument('--steps', type=int, default=100)
+  p.add_argument('--warmup', type=int, default=10)
   p.add_argument('--n', type=int, default=6_000_000)
   p.add_argument('--size', type=int, default=2048)
   p.add_argument('--height', type=int, default=None)
@@ -41,10 +47,13 @@ def parse_args():
   p.add_argument('--seed', type=int, default=0)
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-stages', action='store_true')
-  p.add_argument('--mode', choices=['auto', 'single', 'sharded', 'strips'], default='auto',
+  p.add_argument('--mode', choices=['auto', 'single', 'sharded', 'strips', 'both'], default='auto',
                  help='multi-GPU decomposition: sharded = gaussians by index + pixels by tile-row strip with an '
-                      'all-to-all of projected splats (default for N > 1); strips = replicated gaussians + all-reduce')
+                      'all-to-all of projected splats; strips = replicated gaussians + all-reduce (north_star); '
+                      'auto = both for N > 1 (value = the faster one)')
   p.add_argument('--forward-only', action='store_true')
+  p.add_argument('--launcher', action='store_true',
+                 help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
   return p.parse_args()
 
 
@@ -118,17 +127,23 @@ def stage_breakdown(g, cam, cfg, use_sh):
 
     # the dominant kernel, timed alone through the C-ABI
     grad_image = torch.ones_like(image)
-    gp, gf = torch.zeros_like(g2d), torch.zeros_like(feats)
+    moments = torch.zeros((g2d.shape[0], _lib.MOMENT_ROW), dtype=torch.float32, device=g2d.device)
+    gp, gf = torch.empty_like(g2d), torch.empty_like(feats)
     cfg_c = _lib.raster_config_c(cfg)
     w, h = cam.image_size
     stream = _lib.current_stream(g2d.device)
     tiles_high = (h + cfg.tile_size - 1) // cfg.tile_size
 
     def bwd():
-      _lib.check(lib.ms_raster_bwd(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
-                                   image.data_ptr(), grad_image.data_ptr(), w, h, feats.shape[1], cfg_c,
-                                   gp.data_ptr(), gf.data_ptr(), None, 0, tiles_high, 0, stream), "bench raster_bwd")
+      _lib.check(lib.ms_raster_bwd_moments(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
+                                           image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, moments.data_ptr(),
+                                           0, tiles_high, stream), "bench raster_bwd")
+
+    def fin():
+      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), moments.data_ptr(), g2d.shape[0], gp.data_ptr(),
+                                                gf.data_ptr(), None, stream), "bench raster finalize")
     out['raster_bwd'] = cuda_time_ms(bwd, iters=10, warmup=2)
+    out['raster_bwd_finalize'] = cuda_time_ms(fin, iters=10, warmup=2)
   return out, int(idx.shape[0]), int(o2p.shape[0])
 
 
@@ -179,12 +194,101 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def free_port():
+  import socket
+  with socket.socket() as sock:
+    sock.bind(('127.0.0.1', 0))
+    return sock.getsockname()[1]
+
+
+def respawn_under_torchrun(args):
+  """``--gpus N`` (N > 1) outside a torch.distributed.run environment: re-execute this script under it, one
+  rank per GPU of this node, rendezvous on 127.0.0.1.  Fails loudly when the node has fewer GPUs."""
+  import subprocess
+  have = torch.cuda.device_count()
+  if have < args.gpus:
+    print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
+    sys.exit(2)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  sys.exit(subprocess.call(cmd, env=env))
+
+
+def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
+  """Warm up and time ``args.steps`` frames in one decomposition.  Returns (max-over-ranks seconds, per-rank
+  seconds, bytes this rank exchanges per step, tensors kept for the stage breakdown)."""
+  import torch.distributed as dist
+  from taichi_splatting_amd import render_gaussians
+  from taichi_splatting_amd.distributed import render_strip_step, render_sharded_step, shard_range
+
+  g = scene
+  shard_begin = 0
+  if mode == 'sharded':
+    # every rank generated the same scene (same seed); it keeps only its shard of the gaussians
+    shard_begin, shard_end = shard_range(args.n, world, rank)
+    g = scene[shard_begin:shard_end].clone().contiguous()
+  g.requires_grad_(not args.forward_only)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+  comm = {}
+
+  def step():
+    for t in leaves:
+      t.grad = None
+    if mode == 'sharded':
+      render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
+                          backward=not args.forward_only, index_offset=shard_begin, comm_stats=comm)
+    elif mode == 'strips':
+      render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
+                        backward=not args.forward_only, comm_stats=comm)
+    elif args.forward_only:
+      with torch.no_grad():
+        render_gaussians(g, cam, cfg, use_sh=True)
+    else:
+      render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    step()
+  torch.cuda.synchronize()
+  log(f"[{mode}] {args.warmup} warmup steps done")
+
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  torch.cuda.synchronize()
+  mine = time.perf_counter() - t0            # this rank's own time (before waiting for the slowest)
+  barrier()
+  elapsed = time.perf_counter() - t0
+  per_rank = [mine]
+  if distributed:
+    t = torch.tensor([elapsed, mine], dtype=torch.float64, device=device)
+    all_t = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(all_t, t)
+    elapsed = max(float(x[0]) for x in all_t)
+    per_rank = [float(x[1]) for x in all_t]
+  g.requires_grad_(False)
+  for t in leaves:
+    t.grad = None
+  return elapsed, per_rank, comm, g
+
+
 def main():
   args = parse_args()
+  in_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+  if (args.gpus > 1 or args.launcher) and not in_launcher:
+    respawn_under_torchrun(args)             # does not return
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  distributed = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
+  if in_launcher and world != args.gpus:
+    log(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is what runs and what is reported")
+  distributed = in_launcher
   if distributed:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -194,85 +298,56 @@ def main():
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
 
-  from taichi_splatting_amd import RasterConfig, render_gaussians, _lib
-  from taichi_splatting_amd.distributed import render_strip_step, render_sharded_step, shard_range
+  from taichi_splatting_amd import RasterConfig, _lib
   _lib.load()
-  mode = args.mode
-  if mode == 'auto':
-    mode = 'sharded' if world > 1 else 'single'
+  if args.mode == 'single' or (world == 1 and args.mode == 'auto'):
+    modes = ['single']
+  elif args.mode in ('auto', 'both'):
+    modes = ['strips', 'sharded']
+  else:
+    modes = [args.mode]
 
   cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
   log(f"building scene n={args.n} size={args.size}")
-  g, cam = make_scene(args, device)
+  scene, cam = make_scene(args, device)
   log("scene on device")
   use_sh = True
-  shard_begin = 0
-  if mode == 'sharded':
-    # every rank generated the same scene (same seed); it keeps only its shard of the gaussians
-    shard_begin, shard_end = shard_range(args.n, world, rank)
-    full = g
-    g = g[shard_begin:shard_end].clone().contiguous()
-    del full
-    torch.cuda.empty_cache()
-  g.requires_grad_(not args.forward_only)
-  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
 
-  def step():
-    for t in leaves:
-      t.grad = None
-    if mode == 'sharded':
-      render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
-                          backward=not args.forward_only, index_offset=shard_begin)
-    elif mode == 'strips':
-      render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=use_sh, rank=rank, world_size=world,
-                        backward=not args.forward_only)
-    elif args.forward_only:
-      with torch.no_grad():
-        render_gaussians(g, cam, cfg, use_sh=use_sh)
-    else:
-      r = render_gaussians(g, cam, cfg, use_sh=use_sh)
-      r.image.sum().backward()
+  runs = {}
+  for mode in modes:
+    elapsed, per_rank, comm, g = run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed)
+    ms = elapsed / args.steps * 1e3
+    log(f"[{mode}] timed {args.steps} steps: {ms:.3f} ms/step")
+    runs[mode] = {"ms_per_step": round(ms, 3), "value": round(args.n / (ms * 1e-3) / 1e6, 2),
+                  "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
+                  "rank0_exchange_bytes_per_step": comm or None}
+    if mode != modes[-1]:
+      del g
+      torch.cuda.empty_cache()
+  mode = min(runs, key=lambda m: runs[m]["ms_per_step"])
+  ms_per_step = runs[mode]["ms_per_step"]
+  value = runs[mode]["value"]
 
-  for i in range(args.warmup):
-    step()
-    torch.cuda.synchronize()
-    log(f"warmup step {i} done")
-
-  def barrier():
-    if distributed:
-      dist.barrier()
-    torch.cuda.synchronize()
-
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step()
-  barrier()
-  elapsed = time.perf_counter() - t0
-  if distributed:
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-  ms_per_step = elapsed / args.steps * 1e3
-  log(f"timed {args.steps} steps: {ms_per_step:.3f} ms/step")
-  value = args.n / (ms_per_step * 1e-3) / 1e6
-
+  named = {(6_000_000, 2048, 2048, 3): "config D", (1_000_000, 1920, 1080, 3): "config C",
+           (1_000_000, 1024, 1024, 0): "config B", (6_000_000, 4096, 4096, 3): "config E frame"}
+  label = named.get((args.n, cam.image_size[0], cam.image_size[1], args.sh_degree), "custom")
   result = {
     "metric": "fwd+bwd Msplats/s" if not args.forward_only else "fwd Msplats/s",
-    "value": round(value, 2), "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-    "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    "value": value, "unit": "Msplats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+    "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
     "dtype": "f32", "data": "synthetic",
-    "config": {"workload": f"config D: {args.n} random 3D gaussians, {cam.image_size[0]}x{cam.image_size[1]}, "
+    "config": {"workload": f"{label}: {args.n} random 3D gaussians, {cam.image_size[0]}x{cam.image_size[1]}, "
                            f"SH deg {args.sh_degree}, tile {args.tile}, "
                            f"{'fwd+bwd' if not args.forward_only else 'fwd'} (render_gaussians, loss=image.sum())",
                "n_gaussians": args.n, "image_size": list(cam.image_size), "tile_size": args.tile,
-               "sh_degree": args.sh_degree,
+               "sh_degree": args.sh_degree, "mode": mode,
                "parallelism": {"single": "single GPU",
                                "sharded": f"gaussians sharded x{world} (projection/SH) + tile-row strips x{world} (map/raster), "
                                           "all-to-all of projected splats and of their gradients",
                                "strips": f"replicated gaussians, tile-row strips x{world}, all-reduce of 2D-boundary grads"}[mode]},
   }
+  if world > 1:
+    result["modes"] = runs
 
   if rank == 0 and not args.no_stages and mode == 'single':
     g.requires_grad_(False)
@@ -282,38 +357,50 @@ def main():
     P = w * h
     T = ((w + args.tile - 1) // args.tile) * ((h + args.tile - 1) // args.tile)
     F, D = 3, (args.sh_degree + 1) ** 2
-    passes = (32 + max(1, (T - 1).bit_length()) + 7) // 8
-    alg = algorithmic_bytes(args.n, V, K, P, T, F, D, passes)
+    ref_passes = (32 + max(1, (T - 1).bit_length()) + 7) // 8
+    alg = algorithmic_bytes(args.n, V, K, P, T, F, D, ref_passes)
     dom = 'raster_bwd'
     achieved = alg[dom] / (stages[dom] * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE), valid
-    # only for the workload they were collected on
-    traffic = None
-    try:
-      t = json.load(open(ROOT / 'profiles' / 'r01_raster_hbm_traffic.json'))
-      if (t['workload']['n'], t['workload']['size'], t['workload']['tile']) == (args.n, w, args.tile) and w == h:
-        traffic = t['raster_bwd_f32x3_kernel<16,false>']['traffic_bytes']
-    except Exception:
-      traffic = None
-    result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_f32x3_kernel<%d>" % args.tile,
+    traffic, compute = load_counters(args, w, h)
+    result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_scan_kernel<%d,false>" % args.tile,
                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                           "kernel_ms": round(stages[dom], 4), "algorithmic_bytes": alg[dom],
-                          "note": "alpha-composite passes are VALU/LDS bound at these K*tile^2 (SURVEY 8d)"}
-    frame_bytes = sum(alg.values())
+                          "note": "alpha-composite passes are VALU bound at these K*tile^2 (SURVEY 8d); see compute"}
+    if compute:
+      result["roofline"]["compute"] = compute
+    # frame-level fraction: the reference's formula (6-pass 64-bit key sort) and the bytes THIS design moves
+    # (4-pass depth pre-sort of V pairs + ceil(log2 T / 8) passes over K (tile id, point) pairs)
+    own = dict(alg)
+    own['sort'] = 4 * 16 * V + ((max(1, (T - 1).bit_length()) + 7) // 8) * 16 * K
+    frame_ref, frame_own = sum(alg.values()), sum(own.values())
     result["frame"] = {"V": V, "K": K, "K_per_N": round(K / args.n, 3), "K_per_tile": round(K / T, 1),
-                       "algorithmic_bytes": frame_bytes,
-                       "hbm_frac_of_peak": round(frame_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "algorithmic_bytes": frame_own, "algorithmic_bytes_reference_sort": frame_ref,
+                       "hbm_frac_of_peak": round(frame_own / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "stage_ms": {k: round(v, 4) for k, v in stages.items()}}
 
-  if rank == 0 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result["cpu_baseline"] = cpu_baseline(args)
 
   if rank == 0:
     print(json.dumps(result))
   if distributed:
+    import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
+
+
+def load_counters(args, w, h):
+  """HBM bytes per launch and VALU figures of the dominant kernel from the committed rocprofv3 PMC passes
+  (profiles/r02_raster_bwd_counters.json), valid only for the workload they were collected on."""
+  try:
+    t = json.load(open(ROOT / 'profiles' / 'r02_raster_bwd_counters.json'))
+    wl = t['workload']
+    if (wl['n'], wl['width'], wl['height'], wl['tile']) != (args.n, w, h, args.tile):
+      return None, None
+    return t.get('traffic_bytes'), t.get('compute')
+  except Exception:
+    return None, None
 
 
 if __name__ == '__main__':

@@ -33,7 +33,20 @@
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
 #include "raster_common.h"
 
+// Development builds (tools/abl): -DMS_SCAN_STATS counts chunks / filled lanes / executed pixel steps into
+// g_scan_stats (read with ms_debug_scan_stats); -DMS_SCAN_ABLATE=1 skips the blend phase, =2 the cull + blend.
+#ifndef MS_SCAN_STATS
+#define MS_SCAN_STATS 0
+#endif
+#ifndef MS_SCAN_ABLATE
+#define MS_SCAN_ABLATE 0
+#endif
+
 namespace ms {
+
+#if MS_SCAN_STATS
+__device__ unsigned long long g_scan_stats[8];
+#endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
 constexpr int SCAN_BATCH = 256;               // splats staged per batch (list entries are uint8)
@@ -194,6 +207,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     // wave-wide early out (backward.py:142)
     if (__ballot(__float_as_uint(Ts) > oms_bits) == 0) continue;
 
+#if MS_SCAN_ABLATE == 2
+    continue;
+#endif
     // ---- cull: per sub-patch hit lists (depth order preserved) -----------------------------------------------
     int cnt[4] = {0, 0, 0, 0};
     for (int r = 0; r < count; r += 64) {
@@ -213,6 +229,15 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+#if MS_SCAN_ABLATE == 1
+    continue;
+#endif
+#if MS_SCAN_STATS
+    if (lane == 0) {
+      atomicAdd(&g_scan_stats[0], 1ull);                                              // (wave, batch) visits
+      atomicAdd(&g_scan_stats[1], (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));   // (sub-patch, splat) hits
+    }
+#endif
     // ---- blend: lane = splat, 16 pixel steps per chunk --------------------------------------------------------
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
@@ -239,6 +264,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
         float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
         float h0 = 0.f, h1 = 0.f;
+#if MS_SCAN_STATS
+        int steps_run = 0, lanes_contrib = 0;
+#endif
 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -274,8 +302,20 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
             }
             writelane2_f(Ts, readlane_f(Tk * om, 63), RGs, readlane_f(RGk, 63), p);
+#if MS_SCAN_STATS
+            ++steps_run;
+            lanes_contrib += __builtin_popcountll(__ballot(w != 0.0f));
+#endif
           }
         }
+#if MS_SCAN_STATS
+        if (lane == 0) {
+          atomicAdd(&g_scan_stats[2], 1ull);                                           // chunks
+          atomicAdd(&g_scan_stats[3], (unsigned long long)min(64, n - c0));             // filled lanes
+          atomicAdd(&g_scan_stats[4], (unsigned long long)steps_run);                  // executed pixel steps
+          atomicAdd(&g_scan_stats[5], (unsigned long long)lanes_contrib);              // contributing (pixel, splat) pairs
+        }
+#endif
 
         if (valid) {
           float* acc = &s_acc[buf][idx][0];
@@ -375,6 +415,14 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
   MS_CHECK_LAUNCH();
   return 0;
 }
+
+#if MS_SCAN_STATS
+extern "C" int ms_debug_scan_stats(unsigned long long* out8, int reset) {
+  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_scan_stats), 8 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int64_t n,
                                           float* grad_points7, float* grad_features, float* point_heuristic,

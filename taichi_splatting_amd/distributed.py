@@ -61,11 +61,28 @@ def allreduce_boundary_grads(grad_points: torch.Tensor, grad_features: torch.Ten
   return buf[:, :grad_points.shape[1]], buf[:, grad_points.shape[1]:]
 
 
+def _tie_to_exchange(loss: torch.Tensor, g2: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
+  """Root for ``backward()`` that ALWAYS reaches the 2D boundary tensors, with zero extra gradient.
+
+  The gradient collectives (all-reduce / reverse all-to-all) sit behind ``g2`` / ``f2`` in the graph, so every
+  rank must run them or the others hang.  A ``loss_fn`` may return a constant for an empty strip (more ranks than
+  tile rows, zero-weight rows of a balanced split): such a loss does not depend on the strip image.  Adding
+  ``0 * g2[:1].sum()`` makes the dependency unconditional; the value of the loss reported to the caller is the
+  untouched one."""
+  root = loss
+  for t in (g2, f2):
+    if t.requires_grad:
+      root = root + 0.0 * t[:1].sum().to(loss.dtype)
+  return root
+
+
 def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
                       loss_fn: Callable[[torch.Tensor, Tuple[int, int]], torch.Tensor],
                       use_sh: bool = False, rank: Optional[int] = None, world_size: Optional[int] = None,
-                      group=None, backward: bool = True):
+                      group=None, backward: bool = True, comm_stats: Optional[dict] = None):
   """One forward(+backward) step of the strip-sharded renderer on this rank.
+
+  ``comm_stats`` (optional dict) receives the bytes this rank contributes to the collective per step.
 
   ``loss_fn(image, (row_begin_px, row_end_px))`` must return this rank's share of the loss computed
   from its rows of ``image`` (rows outside the strip are zero).  After the call, ``.grad`` of the
@@ -100,10 +117,13 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
   px_rows = (rows[0] * ts, min(rows[1] * ts, camera_params.image_size[1]))
   loss = loss_fn(rendering.image, px_rows)
   if backward and (g2.requires_grad or f2.requires_grad):
-    loss.backward()
+    # participation in the all-reduce below must not depend on what loss_fn returned on this rank
+    _tie_to_exchange(loss, g2, f2).backward()
     gp = g2.grad if g2.grad is not None else torch.zeros_like(g2)
     gf = f2.grad if f2.grad is not None else torch.zeros_like(f2)
     gp, gf = allreduce_boundary_grads(gp, gf, group)
+    if comm_stats is not None:
+      comm_stats['all_reduce_bytes'] = (gp.shape[1] + gf.shape[1]) * gp.shape[0] * gp.element_size()
     tensors, grads = [], []
     if gaussians2d.requires_grad:
       tensors.append(gaussians2d); grads.append(gp)
@@ -358,7 +378,7 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
                         use_sh: bool = False, rank: Optional[int] = None, world_size: Optional[int] = None,
                         group=None, backward: bool = True, index_offset: int = 0,
                         bounds: Optional[Sequence[int]] = None, exchange=_all_to_all,
-                        point_stats: Optional[dict] = None):
+                        point_stats: Optional[dict] = None, comm_stats: Optional[dict] = None):
   """One forward(+backward) step with gaussians sharded by index and pixels sharded by tile-row strip.
 
   ``shard`` holds only this rank's gaussians (``index_offset`` = global index of its first one).
@@ -400,12 +420,21 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
                                             global_index=indexes, index_offset=index_offset, group=group,
                                             exchange=exchange, return_plan=True)
   rendering = render_projected(gid, g2, f2, d, camera_params, config, tile_rows=rows, crop_to_rows=True)
+  if comm_stats is not None:
+    # forward rows [packed 2D | colour | depth | id], backward rows [d packed 2D | d colour]
+    f, es = f2.shape[1], g2.element_size()
+    sent, received = int(sum(plan.send_counts)), int(sum(plan.recv_counts))
+    comm_stats.update(all_to_all_forward_sent_bytes=sent * (9 + f) * es, all_to_all_forward_received_bytes=received * (9 + f) * es,
+                      all_to_all_backward_sent_bytes=received * (7 + f) * es if backward else 0,
+                      all_to_all_backward_received_bytes=sent * (7 + f) * es if backward else 0)
 
   h = camera_params.image_size[1]
   px_rows = (min(rows[0] * ts, h), min(rows[1] * ts, h))
   loss = loss_fn(rendering.image, px_rows)
-  if backward and loss.requires_grad:
-    loss.backward()
+  if backward and (g2.requires_grad or f2.requires_grad):
+    # the reverse all-to-all in _StripExchange.backward is a collective: every rank runs it, also one whose
+    # loss_fn returned a constant (empty strip)
+    _tie_to_exchange(loss, g2, f2).backward()
 
   if point_stats is not None and (config.compute_visibility or config.compute_point_heuristic):
     # after the backward pass: the split heuristics are accumulated there

@@ -63,3 +63,18 @@ def test_product_has_no_cpu_fallback():
   g = torch.zeros((4, 7))
   with pytest.raises(RuntimeError, match="no CPU fallback"):
     rasterize(g, torch.zeros((4, 1)), torch.zeros((4, 3)), (32, 32), RasterConfig())
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_devices():
+  """`bench.py --gpus N` must launch N ranks itself or refuse: it may never fall back to a 1-GPU number
+  (this container has no GPU, so the request cannot be met)."""
+  import subprocess, sys
+  import torch
+  if torch.cuda.device_count() >= 2:
+    pytest.skip("node has the devices; covered by tests/test_gpu_multi.py")
+  root = Path(__file__).resolve().parent.parent
+  proc = subprocess.run([sys.executable, str(root / 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                        capture_output=True, text=True, timeout=300)
+  assert proc.returncode == 2, proc.stderr[-2000:]
+  assert '--gpus 2 requested' in proc.stderr
+  assert proc.stdout.strip() == ''

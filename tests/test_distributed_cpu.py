@@ -162,3 +162,46 @@ def test_sharded_exchange_matches_full_frame(world):
   ret = mgr.dict()
   mp.spawn(_sharded_worker, args=(world, port, ret), nprocs=world, join=True)
   assert dict(ret) == {r: True for r in range(world)}
+
+
+# ---- a rank whose loss does not depend on its strip still joins the gradient collective -----------
+
+def _constant_loss_worker(rank, world, port, ret):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    from taichi_splatting_amd import RasterConfig
+    from taichi_splatting_amd.distributed import shard_range, exchange_to_strips, _tie_to_exchange
+    from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+    from taichi_splatting_amd.testing import random_2d_gaussians
+    torch.manual_seed(0)
+    size = (96, 80)
+    g = random_2d_gaussians(200, size, scale_factor=1.5)
+    p_full, f_full, d_full = project_gaussians2d(g), g.feature.clone(), g.depths.reshape(-1)
+    tiles_high = (size[1] + 15) // 16
+    bounds = [0] + [tiles_high] * world            # rank 0 renders everything, the other strips are empty
+    b, e = shard_range(p_full.shape[0], world, rank)
+    p = p_full[b:e].clone().requires_grad_(True)
+    f = f_full[b:e].clone().requires_grad_(True)
+    g2, f2, d2, gid2 = exchange_to_strips(p, f, d_full[b:e], size, RasterConfig(), bounds, global_index=torch.arange(b, e))
+    # what a loss_fn does on an empty strip: a constant.  Without the tie this rank would skip the reverse
+    # all-to-all inside backward() and rank 0 would hang in it.
+    loss = (g2.sum() + 2 * f2.sum()) if rank == 0 else torch.zeros(())
+    _tie_to_exchange(loss, g2, f2).backward()
+    visible = p.grad.abs().sum(dim=1) > 0
+    ok = (torch.all(p.grad[visible] == 1.0) and torch.all(f.grad[visible] == 2.0) and int(visible.sum()) > 0
+          and (rank == 0 or g2.shape[0] == 0))
+    ret[rank] = bool(ok)
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_constant_loss_rank_still_joins_reverse_exchange():
+  world = 3
+  port = _free_port()
+  mgr = mp.Manager()
+  ret = mgr.dict()
+  mp.spawn(_constant_loss_worker, args=(world, port, ret), nprocs=world, join=True)
+  assert dict(ret) == {r: True for r in range(world)}

@@ -1,0 +1,40 @@
+"""bench.py launcher path on real devices: `--gpus N` must spawn N RCCL ranks itself and report n_gpus = N in
+both decompositions (tests/test_distributed_cpu.py covers the collectives' logic on gloo)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+SMALL = ['--n', '200000', '--size', '512', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+
+
+def run_bench(*extra):
+  proc = subprocess.run([sys.executable, str(ROOT / 'bench.py'), *SMALL, *extra], capture_output=True, text=True,
+                        timeout=900)
+  assert proc.returncode == 0, proc.stderr[-3000:]
+  lines = [l for l in proc.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, proc.stdout
+  return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_launcher_world_size_one_uses_rccl():
+  """one rank under torch.distributed.run: init_process_group('nccl'), barrier and all_gather on the device"""
+  out = run_bench('--gpus', '1', '--launcher', '--mode', 'both')
+  assert out['n_gpus'] == 1 and set(out['modes']) == {'strips', 'sharded'} if 'modes' in out else out['n_gpus'] == 1
+  assert out['value'] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs")
+def test_two_gpus_both_modes():
+  out = run_bench('--gpus', '2')
+  assert out['n_gpus'] == 2
+  assert set(out['modes']) == {'strips', 'sharded'}
+  for m in out['modes'].values():
+    assert len(m['rank_ms_per_step']) == 2 and m['value'] > 0 and m['rank0_exchange_bytes_per_step']
+  assert out['config']['mode'] in out['modes']

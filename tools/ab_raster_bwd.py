@@ -88,8 +88,20 @@ def main():
       _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), mom.data_ptr(), n, gp1.data_ptr(), gf1.data_ptr(),
                                                 _lib.ptr(he1), stream), "fin")
 
+    import ctypes
+    stats_fn = getattr(lib, 'ms_debug_scan_stats', None)       # only in -DMS_SCAN_STATS builds (tools/build_variant.sh)
+    if stats_fn is not None:
+      stats_fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+      stats_fn(None, 1)
     old(); new_main(); new_fin()
     torch.cuda.synchronize()
+    if stats_fn is not None:
+      out = (ctypes.c_ulonglong * 8)()
+      stats_fn(ctypes.cast(out, ctypes.c_void_p), 1)
+      visits, hits, chunks, lanes, steps, pairs = [int(v) for v in out[:6]]
+      print(f"stats: (wave,batch) visits={visits} (sub-patch,splat) hits={hits} ({hits / o2p.shape[0]:.2f}/overlap) "
+            f"chunks={chunks} fill={lanes / max(chunks, 1):.1f}/64 steps={steps} ({steps / max(chunks, 1):.1f}/chunk) "
+            f"contributing pairs={pairs} ({pairs / max(steps, 1):.1f}/step)")
 
     def report(name, a, b):
       d = (a - b).abs()
