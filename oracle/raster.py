@@ -116,12 +116,38 @@ def _tiles(image_size, tile_size):
   return (w + tile_size - 1) // tile_size, (h + tile_size - 1) // tile_size
 
 
+def reference_tail_order(count: int, group: int):
+  """Order in which the REFERENCE's forward / backward loops visit a tile's ``count`` splats, including the
+  revisits caused by its in-group loop bound ``min(group, count - group_id)`` (forward.py:86-89,
+  backward.py:138-141; it should be ``count - group_id * group``).  In the last, partially filled group the
+  loop runs past the valid entries and re-blends whatever the previous group left in shared memory at those
+  positions.  Returns a list of indices into the tile's list.  ``group`` = threads per
+  block: tile_size^2 in the forward kernel, tile_size^2 / (stride_x * stride_y) in the backward kernel."""
+  order = []
+  groups = (count + group - 1) // group
+  for gi in range(groups):
+    valid = min(group, count - gi * group)
+    visited = min(group, count - gi)
+    for k in range(visited):
+      if k < valid:
+        order.append(gi * group + k)
+      elif gi > 0:
+        order.append((gi - 1) * group + k)       # stale shared-memory entry of the previous group
+      # gi == 0: visited == valid, nothing stale
+  return order
+
+
 def forward(points, feats, ranges, o2p, image_size, cfg, tile_rows: Optional[Tuple[int, int]] = None,
-            return_borderline: bool = False):
+            return_borderline: bool = False, emulate_reference_loop_bound: bool = False,
+            reference_group: Optional[int] = None):
   """Returns image (H,W,F), alpha (H,W), visibility (V,) [, borderline (H,W) bool].
 
   ``borderline`` marks pixels where some splat's alpha lies within 1e-6 (relative) of the
   ``alpha_threshold`` gate: a float32 implementation may legitimately flip that gate.
+
+  ``emulate_reference_loop_bound`` reproduces the reference's loop-bound defect (see
+  ``reference_tail_order``; ``reference_group`` defaults to tile_size^2, the forward kernel's block size) so
+  that the deviation of this library — which visits every splat exactly once — can be quantified.
   """
   w, h = image_size
   ts = cfg.tile_size
@@ -143,6 +169,8 @@ def forward(points, feats, ranges, o2p, image_size, cfg, tile_rows: Optional[Tup
     W = torch.where(inb, torch.zeros(P, dtype=dtype), torch.ones(P, dtype=dtype))
     if end > start:
       ids = o2p[start:end].long()
+      if emulate_reference_loop_bound:
+        ids = ids[torch.tensor(reference_tail_order(end - start, reference_group or ts * ts), dtype=torch.long)]
       g, f = points[ids], feats[ids]
       a_raw = g[None, :, 6] * pdf(pix, g, cfg.antialias)                  # (P, S)
       a = torch.clamp_max(a_raw, cfg.clamp_max_alpha)
@@ -167,6 +195,10 @@ def forward(points, feats, ranges, o2p, image_size, cfg, tile_rows: Optional[Tup
         first = torch.argmax(sat.to(torch.int8), dim=1)
         C = torch.where(any_sat[:, None], f[first], torch.zeros((P, F), dtype=dtype))
         W = W_after[:, -1]
+        # forward.py:114-126 keeps adding the blend weights to `visibility` in this mode too.  The reference
+        # stops only when all 32 lanes of a warp are saturated (forward.py:92-94), which depends on its
+        # thread -> pixel map; the oracle accumulates the untruncated weights (an upper bound of the reference's).
+        visibility.index_add_(0, ids, weight.sum(0))
       if return_borderline:
         borderline[py[inb], px[inb]] = bl[inb]
     image[py[inb], px[inb]] = C[inb]
@@ -177,6 +209,34 @@ def forward(points, feats, ranges, o2p, image_size, cfg, tile_rows: Optional[Tup
   if return_borderline:
     return image, alpha_img, visibility, borderline
   return image, alpha_img, visibility
+
+
+def gate_margin(points, ranges, o2p, image_size, cfg, tile_rows: Optional[Tuple[int, int]] = None):
+  """Per splat: min over the pixels of the tiles it is listed in of |alpha_pt * g / alpha_threshold - 1|, the
+  relative distance of the nearest (pixel, splat) pair to the blend gate ``alpha > alpha_threshold``
+  (forward.py:99-101).  A float32 implementation evaluates alpha_pt * g to ~1e-6 relative, so pairs closer than
+  that may legitimately fall on the other side of the gate; tests drop such splats from a scene ("gate-stable
+  scene") and can then compare images AND gradients without a borderline allowance."""
+  w, h = image_size
+  ts = cfg.tile_size
+  tiles_wide, tiles_high = _tiles(image_size, ts)
+  dtype = points.dtype
+  margin = torch.full((points.shape[0],), float('inf'), dtype=dtype)
+  ranges = ranges.reshape(-1, 2)
+  r0, r1 = (0, tiles_high) if tile_rows is None else tile_rows
+  for tile_id in range(r0 * tiles_wide, r1 * tiles_wide):
+    start, end = int(ranges[tile_id, 0]), int(ranges[tile_id, 1])
+    if end <= start:
+      continue
+    px, py, inb, pix = _tile_pixels(tile_id, tiles_wide, ts, w, h, dtype)
+    if not bool(inb.any()):
+      continue
+    ids = o2p[start:end].long()
+    g = points[ids]
+    a_raw = g[None, :, 6] * pdf(pix[inb], g, cfg.antialias)
+    m = (a_raw / cfg.alpha_threshold - 1).abs().min(dim=0).values
+    margin.scatter_reduce_(0, ids, m, reduce='amin')
+  return margin
 
 
 def backward(points, feats, ranges, o2p, image, grad_image, image_size, cfg,

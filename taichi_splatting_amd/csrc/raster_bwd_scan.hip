@@ -25,9 +25,10 @@
 //     (X, Y) = pixel in the splat's normalised frame) plus sum w G_c: every geometric gradient of
 //     generic.py:321-336 is a per-splat LINEAR map of these sums, applied once per gaussian by
 //     raster_moments_finalize_kernel (or by the fused projection/SH backward) instead of once per pixel;
-//   * a chunk ends with one ds_add_f32 per moment into the tile's accumulators (lanes = distinct splats, so no
-//     same-address serialisation), and a batch ends with ONE 64-byte, line-aligned row of global float atomics
-//     per (tile, splat): 16 lanes commit the 16 floats of moments[id] in one instruction.
+//   * a chunk ends with a plain read-add-write of the lane's sums into the WAVE'S OWN LDS row of that splat (LDS
+//     float atomics cost ~160 cycles per instruction on gfx950 and are avoided), and a pass over the staged batch
+//     ends with ONE 64-byte, line-aligned row of global float atomics per (8x8 patch, splat): 16 lanes commit the
+//     16 floats of moments[id] in one instruction.
 //
 // VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~56 instructions / (lanes filled) ~= 18 wave
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
@@ -49,7 +50,6 @@ __device__ unsigned long long g_scan_stats[8];
 #endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
-constexpr int SCAN_BATCH = 256;               // splats staged per batch (list entries are uint8)
 
 // Inclusive prefix product / sum over the 64 lanes: row_shr:1,2,4,8 build the 16-lane row prefixes, row_bcast:15
 // (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row totals — six DPP instructions.  Lanes without a source
@@ -125,14 +125,18 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                        const float* __restrict__ image, const float* __restrict__ grad_image,
                        FastParams rp, float* __restrict__ moments) {
   constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
-  constexpr int BATCH = SCAN_BATCH;
+  constexpr int BATCH = TS == 8 ? 128 : 256;     // splats staged per batch, shared by the tile's waves (uint8 indices)
+  constexpr int CAP = TS == 8 ? 128 : TS == 16 ? 160 : 96;   // patch hits a wave takes on per pass (>= 64: a pass always advances)
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= BATCH;   // one staged splat per thread, gathered one batch ahead
-  // 12 + 18 (22 with heuristics) + 2 + 4 KB at tile 16: four workgroups per CU
+  // tile 16: 12 KB records + 1 KB ids + 4 x (5.6 KB accumulators + 0.8 KB lists) = 38.6 KB: four workgroups per CU
   __shared__ float4 s_rec[BATCH * 3];
-  __shared__ float s_acc[2][BATCH][NACC];        // odd row length: zeroing, ds_add and the transposed commit stay spread over the banks
-  __shared__ int32_t s_id[2][BATCH];
-  __shared__ uint8_t s_list[WAVES][4][BATCH];
+  __shared__ int32_t s_id[BATCH];
+  // PER-WAVE gradient accumulators, one row per splat of the wave's patch list: plain read-add-write, no LDS
+  // atomics (ds_add_f32 costs ~160 LDS cycles per instruction on gfx950, tools/ubench_scan.hip)
+  __shared__ float s_acc[WAVES][CAP][NACC];
+  __shared__ uint8_t s_plist[WAVES][CAP];        // patch-list position -> staged index
+  __shared__ uint8_t s_list[WAVES][4][CAP];      // per sub-patch: patch-list positions of its hits, depth ordered
 
   const int tile_id = rp.tile_begin + blockIdx.x;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
@@ -153,6 +157,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   const float oms = rp.one_minus_saturate;
   const uint32_t oms_bits = __float_as_uint(oms);     // T >= 0: the float order is the order of the bit patterns
 
+  // accumulators start at zero; the commit of a pass re-zeroes exactly what it read
+  for (int i = lane; i < CAP * NACC; i += 64) (&s_acc[wave][0][0])[i] = 0.0f;
+
   const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
 
   Raw raw;
@@ -162,21 +169,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     if (t < BATCH && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
   }
 
-  // transposed commit of a finished batch: 16 consecutive lanes add the 16 floats of one splat's moments row
-  auto commit = [&](int buf, int n) {
-    for (int i = t; i < n * MOMENT_ROW; i += THREADS) {
-      const int slot = i >> 4, k = i & 15;
-      if (k < NACC) {
-        const float v = s_acc[buf][slot][k];
-        if (v != 0.0f) atomic_add_noret(moments + (size_t)(uint32_t)s_id[buf][slot] * MOMENT_ROW + k, v);
-      }
-    }
-  };
-
-  int b = 0, prev_count = 0;
-  for (int begin = start; begin < end; begin += BATCH, ++b) {
+  for (int begin = start; begin < end; begin += BATCH) {
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
-    const int buf = b & 1;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
     if (__syncthreads_and(__float_as_uint(Ts) <= oms_bits)) break;
@@ -184,9 +178,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     if (PIPELINED) {
       if (t < count) {
         write_scan_record(raw, rp.alpha_threshold, &s_rec[t * 3]);
-        s_id[buf][t] = raw.id;
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) s_acc[buf][t][k] = 0.0f;
+        s_id[t] = raw.id;
       }
       if (t < BATCH && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
       if (t < BATCH && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
@@ -194,142 +186,170 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       for (int s = t; s < count; s += THREADS) {
         const Raw r = load_raw(points, feats, o2p[begin + s]);
         write_scan_record(r, rp.alpha_threshold, &s_rec[s * 3]);
-        s_id[buf][s] = r.id;
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) s_acc[buf][s][k] = 0.0f;
+        s_id[s] = r.id;
       }
     }
     __syncthreads();
 
-    if (b > 0) commit(buf ^ 1, prev_count);
-    prev_count = count;
-
     // wave-wide early out (backward.py:142)
     if (__ballot(__float_as_uint(Ts) > oms_bits) == 0) continue;
-
 #if MS_SCAN_ABLATE == 2
     continue;
 #endif
-    // ---- cull: per sub-patch hit lists (depth order preserved) -----------------------------------------------
-    int cnt[4] = {0, 0, 0, 0};
-    for (int r = 0; r < count; r += 64) {
-      const int j = r + lane;
-      const bool in = j < count;
-      const float4 q0 = s_rec[j * 3 + 0], q1 = s_rec[j * 3 + 1], q2 = s_rec[j * 3 + 2];
+
+    // From here to the next barrier the wave works alone: it walks the staged batch in passes of at most CAP
+    // patch hits (one pass per batch unless most staged splats touch this 8x8 patch).
+    int r = 0;
+    while (r < count) {
+      // ---- cull: patch list + per sub-patch hit lists (depth order preserved) ---------------------------------
+      int pcount = 0;
+      int cnt[4] = {0, 0, 0, 0};
+      while (r < count) {
+        const int j = r + lane;
+        const bool in = j < count;
+        const float4 q0 = s_rec[j * 3 + 0], q1 = s_rec[j * 3 + 1], q2 = s_rec[j * 3 + 2];
+        bool hit[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
-        const bool hit = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
-        const unsigned long long m = __ballot(hit);
-        const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (hit) s_list[wave][q][pos] = (uint8_t)j;
-        cnt[q] += __builtin_popcountll(m);
+        for (int q = 0; q < 4; ++q) {
+          const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
+          hit[q] = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
+        }
+        const bool any = hit[0] || hit[1] || hit[2] || hit[3];
+        const unsigned long long many = __ballot(any);
+        const int nany = __builtin_popcountll(many);
+        if (pcount + nany > CAP) break;          // next pass (nany <= 64 <= CAP: an empty list always takes the group)
+        const int ppos = pcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u));
+        if (any) s_plist[wave][ppos] = (uint8_t)j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned long long m = __ballot(hit[q]);
+          const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (hit[q]) s_list[wave][q][pos] = (uint8_t)ppos;
+          cnt[q] += __builtin_popcountll(m);
+        }
+        pcount += nany;
+        r += 64;
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #if MS_SCAN_ABLATE == 1
-    continue;
+      continue;
 #endif
 #if MS_SCAN_STATS
-    if (lane == 0) {
-      atomicAdd(&g_scan_stats[0], 1ull);                                              // (wave, batch) visits
-      atomicAdd(&g_scan_stats[1], (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));   // (sub-patch, splat) hits
-    }
+      if (lane == 0) {
+        atomicAdd(&g_scan_stats[0], 1ull);                                                      // passes
+        atomicAdd(&g_scan_stats[1], (unsigned long long)(cnt[0] + cnt[1] + cnt[2] + cnt[3]));   // (sub-patch, splat) hits
+        atomicAdd(&g_scan_stats[6], (unsigned long long)pcount);                                // (patch, splat) hits
+      }
 #endif
-    // ---- blend: lane = splat, 16 pixel steps per chunk --------------------------------------------------------
+
+      // ---- blend: lane = splat, 16 pixel steps per chunk ------------------------------------------------------
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
-      if (n == 0) continue;
-      const unsigned long long alive = __ballot(__float_as_uint(Ts) > oms_bits);
-      if (((alive >> (16 * q)) & 0xffffull) == 0) continue;
-      const int pbase = q * 16;
-      const float fx = (float)(patch_x + (q & 1) * 4) + 0.5f, fy = (float)(patch_y + (q >> 1) * 4) + 0.5f;
+      for (int q = 0; q < 4; ++q) {
+        const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
+        if (n == 0) continue;
+        const unsigned long long alive = __ballot(__float_as_uint(Ts) > oms_bits);
+        if (((alive >> (16 * q)) & 0xffffull) == 0) continue;
+        const int pbase = q * 16;
+        const float fx = (float)(patch_x + (q & 1) * 4) + 0.5f, fy = (float)(patch_y + (q >> 1) * 4) + 0.5f;
 
 #pragma unroll 1
-      for (int c0 = 0; c0 < n; c0 += 64) {
-        const bool valid = c0 + lane < n;
-        const int idx = valid ? (int)s_list[wave][q][c0 + lane] : 0;
-        const float4 q0 = s_rec[idx * 3 + 0], q1 = s_rec[idx * 3 + 1], q2 = s_rec[idx * 3 + 2];
-        const float A = q0.z, B = q0.w, C = q1.x, D = q1.y;
-        const float nl2a = valid ? q1.z : __builtin_inff();       // idle lanes: alpha g = exp2(-inf) = 0
-        const float f0 = q1.w, f1 = q2.x, f2 = q2.y;
-        const float dx0 = fx - q0.x, dy0 = fy - q0.y;             // first pixel centre of the sub-patch - mean
-        const float X00 = A * dx0 + B * dy0, Y00 = C * dx0 + D * dy0;
-        // (X', Y') at the first pixel of each of the four pixel rows; a step adds x * (A, C)
-        const float Xr[4] = {X00, X00 + B, __builtin_fmaf(B, 2.0f, X00), __builtin_fmaf(B, 3.0f, X00)};
-        const float Yr[4] = {Y00, Y00 + D, __builtin_fmaf(D, 2.0f, Y00), __builtin_fmaf(D, 3.0f, Y00)};
+        for (int c0 = 0; c0 < n; c0 += 64) {
+          const bool valid = c0 + lane < n;
+          const int pos = valid ? (int)s_list[wave][q][c0 + lane] : 0;
+          const int idx = (int)s_plist[wave][pos];
+          const float4 q0 = s_rec[idx * 3 + 0], q1 = s_rec[idx * 3 + 1], q2 = s_rec[idx * 3 + 2];
+          const float A = q0.z, B = q0.w, C = q1.x, D = q1.y;
+          const float nl2a = valid ? q1.z : __builtin_inff();       // idle lanes: alpha g = exp2(-inf) = 0
+          const float f0 = q1.w, f1 = q2.x, f2 = q2.y;
+          const float dx0 = fx - q0.x, dy0 = fy - q0.y;             // first pixel centre of the sub-patch - mean
+          const float X00 = A * dx0 + B * dy0, Y00 = C * dx0 + D * dy0;
+          // (X', Y') at the first pixel of each of the four pixel rows; a step adds x * (A, C)
+          const float Xr[4] = {X00, X00 + B, __builtin_fmaf(B, 2.0f, X00), __builtin_fmaf(B, 3.0f, X00)};
+          const float Yr[4] = {Y00, Y00 + D, __builtin_fmaf(D, 2.0f, Y00), __builtin_fmaf(D, 3.0f, Y00)};
 
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        float h0 = 0.f, h1 = 0.f;
+          float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
+          float h0 = 0.f, h1 = 0.f;
 #if MS_SCAN_STATS
-        int steps_run = 0, lanes_contrib = 0;
+          int steps_run = 0, lanes_contrib = 0;
 #endif
 
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int p = pbase + i;
-          const float Tin = readlane_f(Ts, p);
-          if (__float_as_uint(Tin) > oms_bits) {                  // saturated / out-of-image pixel: skipped
-            const float cx = (float)(i & 3);
-            const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
-            const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
-            const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X, X, __builtin_fmaf(Y, Y, nl2a)));
-            const bool contrib = a_raw > rp.alpha_threshold;
-            const float a_clamped = min_f32(a_raw, rp.clamp_max_alpha);
-            const float a = contrib ? a_clamped : 0.0f;
-            const float om = 1.0f - a;
-            // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
-            const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
-            const float w = Tk > oms ? a * Tk : 0.0f;                             // saturation skip (backward.py:154)
-            const float g0 = readlane_f(G0s, p), g1 = readlane_f(G1s, p), g2 = readlane_f(G2s, p);
-            const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
-            // <R, G> after this splat: R -= f w  (backward.py:171-174)
-            const float RGk = readlane_f(RGs, p) - wave_scan_add(w * fG);
-            // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
-            const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
-            // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha)
-            const float q = w != 0.0f ? ag * a_raw : 0.0f;
-            const float qX = q * X, qY = q * Y;
-            m0 += q; m1 += qX; m2 += qY;
-            m3 = __builtin_fmaf(qX, X, m3); m4 = __builtin_fmaf(qX, Y, m4); m5 = __builtin_fmaf(qY, Y, m5);
-            a0 = __builtin_fmaf(w, g0, a0); a1 = __builtin_fmaf(w, g1, a1); a2 = __builtin_fmaf(w, g2, a2);
-            if (HEUR) {                                           // backward.py:190-194
-              const float agm = w != 0.0f ? ag : 0.0f;
-              h0 = __builtin_fmaf(agm, agm, h0);
-              h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
-            }
-            writelane2_f(Ts, readlane_f(Tk * om, 63), RGs, readlane_f(RGk, 63), p);
+          for (int i = 0; i < 16; ++i) {
+            const int p = pbase + i;
+            const float Tin = readlane_f(Ts, p);
+            if (__float_as_uint(Tin) > oms_bits) {                  // saturated / out-of-image pixel: skipped
+              const float cx = (float)(i & 3);
+              const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
+              const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
+              const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X, X, __builtin_fmaf(Y, Y, nl2a)));
+              const bool contrib = a_raw > rp.alpha_threshold;
+              const float a_clamped = min_f32(a_raw, rp.clamp_max_alpha);
+              const float a = contrib ? a_clamped : 0.0f;
+              const float om = 1.0f - a;
+              // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
+              const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
+              const float w = Tk > oms ? a * Tk : 0.0f;                             // saturation skip (backward.py:154)
+              const float g0 = readlane_f(G0s, p), g1 = readlane_f(G1s, p), g2 = readlane_f(G2s, p);
+              const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
+              // <R, G> after this splat: R -= f w  (backward.py:171-174)
+              const float RGk = readlane_f(RGs, p) - wave_scan_add(w * fG);
+              // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
+              const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
+              // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha)
+              const float q_ = w != 0.0f ? ag * a_raw : 0.0f;
+              const float qX = q_ * X, qY = q_ * Y;
+              m0 += q_; m1 += qX; m2 += qY;
+              m3 = __builtin_fmaf(qX, X, m3); m4 = __builtin_fmaf(qX, Y, m4); m5 = __builtin_fmaf(qY, Y, m5);
+              a0 = __builtin_fmaf(w, g0, a0); a1 = __builtin_fmaf(w, g1, a1); a2 = __builtin_fmaf(w, g2, a2);
+              if (HEUR) {                                           // backward.py:190-194
+                const float agm = w != 0.0f ? ag : 0.0f;
+                h0 = __builtin_fmaf(agm, agm, h0);
+                h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+              }
+              writelane2_f(Ts, readlane_f(Tk * om, 63), RGs, readlane_f(RGk, 63), p);
 #if MS_SCAN_STATS
-            ++steps_run;
-            lanes_contrib += __builtin_popcountll(__ballot(w != 0.0f));
+              ++steps_run;
+              lanes_contrib += __builtin_popcountll(__ballot(w != 0.0f));
 #endif
+            }
+          }
+#if MS_SCAN_STATS
+          if (lane == 0) {
+            atomicAdd(&g_scan_stats[2], 1ull);                                           // chunks
+            atomicAdd(&g_scan_stats[3], (unsigned long long)min(64, n - c0));             // filled lanes
+            atomicAdd(&g_scan_stats[4], (unsigned long long)steps_run);                  // executed pixel steps
+            atomicAdd(&g_scan_stats[5], (unsigned long long)lanes_contrib);              // contributing (pixel, splat) pairs
+          }
+#endif
+
+          // this wave's row of the splat: the lanes of a chunk hold distinct splats, chunks run one after the other
+          if (valid) {
+            float* row = &s_acc[wave][pos][0];
+            const float v[11] = {m0, m1, m2, m3, m4, m5, a0, a1, a2, h0, h1};
+#pragma unroll
+            for (int k = 0; k < NACC; ++k) row[k] += v[k];
           }
         }
-#if MS_SCAN_STATS
-        if (lane == 0) {
-          atomicAdd(&g_scan_stats[2], 1ull);                                           // chunks
-          atomicAdd(&g_scan_stats[3], (unsigned long long)min(64, n - c0));             // filled lanes
-          atomicAdd(&g_scan_stats[4], (unsigned long long)steps_run);                  // executed pixel steps
-          atomicAdd(&g_scan_stats[5], (unsigned long long)lanes_contrib);              // contributing (pixel, splat) pairs
-        }
-#endif
+      }
 
-        if (valid) {
-          float* acc = &s_acc[buf][idx][0];
-          const float v[11] = {m0, m1, m2, m3, m4, m5, a0, a1, a2, h0, h1};
-#pragma unroll
-          for (int k = 0; k < NACC; ++k)
-            __hip_atomic_fetch_add(acc + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // ---- commit the pass: ONE 64-byte row of global float atomics per (patch, splat), 16 lanes per row -----
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < pcount * MOMENT_ROW; i += 64) {
+        const int e = i >> 4, k = i & 15;
+        if (k < NACC) {
+          const float v = s_acc[wave][e][k];
+          if (v != 0.0f) {
+            atomic_add_noret(moments + (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k, v);
+            s_acc[wave][e][k] = 0.0f;
+          }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
-
-  __syncthreads();
-  if (b > 0) commit((b - 1) & 1, prev_count);
 }
 
 // Moments -> gradients of the packed 2D gaussian and its colour (one thread per point; plain stores).
