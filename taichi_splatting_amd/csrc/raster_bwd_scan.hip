@@ -15,8 +15,8 @@
 //     the hits into per-sub-patch lists (ballot + mbcnt, order preserving => still depth sorted);
 //   * a sub-patch list is consumed in chunks of 64 hits with ONE SPLAT PER LANE.  The 16 pixels of the
 //     sub-patch are visited one after the other; the pixel (its coordinates, transmittance T, dL/dC and the
-//     colour still to come <R, G>) is wave-uniform and lives in SGPRs (v_readlane from state registers whose lane
-//     p holds pixel p).  The front-to-back recurrence over the 64 splats of the chunk is two DPP prefix scans:
+//     colour still to come <R, G>) is wave-uniform: every lane reads it from the same LDS address (broadcast),
+//     one step ahead of its use.  The front-to-back recurrence over the 64 splats of the chunk is two DPP prefix scans:
 //         T_k  = T_in * prod_{j<k} (1 - a_j)            (multiplicative, exclusive: wave_shr:1 + 6 v_mul_f32_dpp)
 //         S_k  = sum_{j<=k} w_j <f_j, G>                 (additive, inclusive: 6 v_add_f32_dpp)
 //     so each lane knows the T and <R, G> its splat sees at this pixel, evaluates d(alpha) and accumulates ITS
@@ -69,20 +69,6 @@ __device__ __forceinline__ float wave_scan_mul(float v) { MS_SCAN_ASM("v_mul_f32
 __device__ __forceinline__ float wave_scan_add(float v) { MS_SCAN_ASM("v_add_f32_dpp"); return v; }
 #undef MS_SCAN_ASM
 
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-// state[lane] = value for two state registers at once: v_writelane_b32 with wave-uniform (SGPR) value and lane.
-// gfx9 VALU instructions read at most one SGPR, so the lane select goes through M0 (which nothing else in this
-// kernel uses: gfx9 LDS instructions do not need it).
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void writelane2_f(float& s0, float v0, float& s1, float v1, int lane) {
-  asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-               : "+v"(s0), "+v"(s1) : "s"(v0), "s"(v1), "s"(lane) : "m0");
-}
-#pragma clang diagnostic pop
-
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 // 48-byte LDS record of a staged splat:
@@ -126,10 +112,11 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                        FastParams rp, float* __restrict__ moments) {
   constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
   constexpr int BATCH = TS == 8 ? 128 : 256;     // splats staged per batch, shared by the tile's waves (uint8 indices)
-  constexpr int CAP = TS == 8 ? 128 : TS == 16 ? 160 : 96;   // patch hits a wave takes on per pass (>= 64: a pass always advances)
+  constexpr int CAP = TS == 32 ? 96 : 128;   // patch hits a wave takes on per pass (>= 64: a pass always advances)
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= BATCH;   // one staged splat per thread, gathered one batch ahead
-  // tile 16: 12 KB records + 1 KB ids + 4 x (5.6 KB accumulators + 0.8 KB lists) = 38.6 KB: four workgroups per CU
+  // tile 16: 12 KB records + 1 KB ids + 4 x (4.5 KB accumulators + 0.6 KB lists + 1.25 KB pixels) = 38.5 KB: four
+  // workgroups per CU
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];
   // PER-WAVE gradient accumulators, one row per splat of the wave's patch list: plain read-add-write, no LDS
@@ -137,6 +124,11 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   __shared__ float s_acc[WAVES][CAP][NACC];
   __shared__ uint8_t s_plist[WAVES][CAP];        // patch-list position -> staged index
   __shared__ uint8_t s_list[WAVES][4][CAP];      // per sub-patch: patch-list positions of its hits, depth ordered
+  // per-pixel data, read by ALL lanes of the wave at the pixel's step (same address: LDS broadcast; v_readlane
+  // from state registers costs ~12-16 cycles per value on gfx950, tools/ubench_scan.hip):
+  // [dL/dC.rgb, T] and <R, G>; entry p = 16 * sub-patch + 4 * y + x
+  __shared__ float4 s_pix[WAVES][64];
+  __shared__ float s_rg[WAVES][64];
 
   const int tile_id = rp.tile_begin + blockIdx.x;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
@@ -147,13 +139,18 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // pixel state: lane p = 16 * sub + 4 * y + x holds pixel (x, y) of sub-patch `sub` (sub-patches 2 x 2)
   const int sub = lane >> 4;
   const int pix_x = patch_x + (sub & 1) * 4 + (lane & 3), pix_y = patch_y + (sub >> 1) * 4 + ((lane >> 2) & 3);
-  float G0s = 0.f, G1s = 0.f, G2s = 0.f, RGs = 0.f, Ts = 0.f;     // T = 0: out-of-image pixels never blend
-  if (pix_x < rp.width && pix_y < rp.height) {
-    const int64_t p = (int64_t)pix_y * rp.width + pix_x;
-    G0s = grad_image[p * 3 + 0]; G1s = grad_image[p * 3 + 1]; G2s = grad_image[p * 3 + 2];
-    RGs = image[p * 3 + 0] * G0s + image[p * 3 + 1] * G1s + image[p * 3 + 2] * G2s;   // <R, G>, R = forward image
-    Ts = 1.0f;
+  {
+    float G0 = 0.f, G1 = 0.f, G2 = 0.f, RG = 0.f, T = 0.f;        // T = 0: out-of-image pixels never blend
+    if (pix_x < rp.width && pix_y < rp.height) {
+      const int64_t p = (int64_t)pix_y * rp.width + pix_x;
+      G0 = grad_image[p * 3 + 0]; G1 = grad_image[p * 3 + 1]; G2 = grad_image[p * 3 + 2];
+      RG = image[p * 3 + 0] * G0 + image[p * 3 + 1] * G1 + image[p * 3 + 2] * G2;   // <R, G>, R = forward image
+      T = 1.0f;
+    }
+    s_pix[wave][lane] = make_float4(G0, G1, G2, T);
+    s_rg[wave][lane] = RG;
   }
+  const bool last_lane = lane == 63;
   const float oms = rp.one_minus_saturate;
   const uint32_t oms_bits = __float_as_uint(oms);     // T >= 0: the float order is the order of the bit patterns
 
@@ -173,7 +170,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
-    if (__syncthreads_and(__float_as_uint(Ts) <= oms_bits)) break;
+    if (__syncthreads_and(__float_as_uint(s_pix[wave][lane].w) <= oms_bits)) break;
 
     if (PIPELINED) {
       if (t < count) {
@@ -192,7 +189,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     __syncthreads();
 
     // wave-wide early out (backward.py:142)
-    if (__ballot(__float_as_uint(Ts) > oms_bits) == 0) continue;
+    if (__ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits) == 0) continue;
 #if MS_SCAN_ABLATE == 2
     continue;
 #endif
@@ -248,7 +245,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       for (int q = 0; q < 4; ++q) {
         const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
         if (n == 0) continue;
-        const unsigned long long alive = __ballot(__float_as_uint(Ts) > oms_bits);
+        const unsigned long long alive = __ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits);
         if (((alive >> (16 * q)) & 0xffffull) == 0) continue;
         const int pbase = q * 16;
         const float fx = (float)(patch_x + (q & 1) * 4) + 0.5f, fy = (float)(patch_y + (q >> 1) * 4) + 0.5f;
@@ -274,11 +271,17 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           int steps_run = 0, lanes_contrib = 0;
 #endif
 
+          // pixel data of the step after the current one is requested before the current step is evaluated
+          float4 pg = s_pix[wave][pbase];
+          float prg = s_rg[wave][pbase];
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int p = pbase + i;
-            const float Tin = readlane_f(Ts, p);
-            if (__float_as_uint(Tin) > oms_bits) {                  // saturated / out-of-image pixel: skipped
+            const float4 cur = pg;
+            const float RGin = prg;
+            if (i < 15) { pg = s_pix[wave][p + 1]; prg = s_rg[wave][p + 1]; }
+            const float Tin = cur.w;
+            if (__ballot(__float_as_uint(Tin) > oms_bits) != 0) {   // wave-uniform: saturated / out-of-image pixels are skipped
               const float cx = (float)(i & 3);
               const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
               const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
@@ -290,10 +293,10 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
               const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
               const float w = Tk > oms ? a * Tk : 0.0f;                             // saturation skip (backward.py:154)
-              const float g0 = readlane_f(G0s, p), g1 = readlane_f(G1s, p), g2 = readlane_f(G2s, p);
+              const float g0 = cur.x, g1 = cur.y, g2 = cur.z;
               const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
               // <R, G> after this splat: R -= f w  (backward.py:171-174)
-              const float RGk = readlane_f(RGs, p) - wave_scan_add(w * fG);
+              const float RGk = RGin - wave_scan_add(w * fG);
               // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
               const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha)
@@ -307,7 +310,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                 h0 = __builtin_fmaf(agm, agm, h0);
                 h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
               }
-              writelane2_f(Ts, readlane_f(Tk * om, 63), RGs, readlane_f(RGk, 63), p);
+              // the last lane holds the pixel's state after the whole chunk
+              if (last_lane) { s_pix[wave][p].w = Tk * om; s_rg[wave][p] = RGk; }
 #if MS_SCAN_STATS
               ++steps_run;
               lanes_contrib += __builtin_popcountll(__ballot(w != 0.0f));

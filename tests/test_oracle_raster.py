@@ -156,3 +156,104 @@ def test_mapper_membership_is_bruteforce_sat():
           want.add((i, x, y))
   border = omap.borderline_pairs(p, size, 16, thr)
   assert (got ^ want) <= border, sorted(got ^ want)[:5]
+
+
+# ---- second opinion: literal scalar loops (oracle/raster_scalar.py) vs the vectorised oracle ------------------
+
+def test_scalar_loop_oracle_agrees_on_multi_group_tiles():
+  # two 16x16 tiles with > 256 splats each (several groups of the reference's staging), depth ties, out-of-image
+  # columns (width 28 is not a tile multiple); forward image / alpha / visibility and all gradients
+  from oracle import raster_scalar as osc
+  torch.manual_seed(5)
+  size = (28, 16)
+  g = random_2d_gaussians(800, size, scale_factor=2.5, alpha_range=(0.05, 0.9))
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, 16)
+  assert int((ranges[..., 1] - ranges[..., 0]).max()) > 256
+  o2p_t, ranges_t = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  cfg = orast.Cfg(compute_point_heuristic=True)
+  img, alpha, vis = orast.forward(p, f, ranges_t, o2p_t, size, cfg)
+  G = torch.randn_like(img)
+  gp, gf, heur = orast.backward(p, f, ranges_t, o2p_t, img, G, size, cfg)
+
+  rl = [tuple(int(v) for v in r) for r in ranges.reshape(-1, 2)]
+  img_s, alpha_s, vis_s = osc.forward(p.tolist(), f.tolist(), rl, o2p.tolist(), size)
+  assert torch.allclose(torch.tensor(img_s, dtype=torch.float64), img, atol=1e-12)
+  assert torch.allclose(torch.tensor(alpha_s, dtype=torch.float64), alpha, atol=1e-12)
+  assert torch.allclose(torch.tensor(vis_s, dtype=torch.float64), vis, atol=1e-11)
+  gp_s, gf_s, heur_s = osc.backward(p.tolist(), f.tolist(), rl, o2p.tolist(), img.tolist(), G.tolist(), size)
+  scale = float(gp.abs().max())
+  assert torch.allclose(torch.tensor(gp_s, dtype=torch.float64), gp, atol=1e-11 * scale, rtol=1e-9)
+  assert torch.allclose(torch.tensor(gf_s, dtype=torch.float64), gf, atol=1e-12, rtol=1e-9)
+  assert torch.allclose(torch.tensor(heur_s, dtype=torch.float64), heur, atol=1e-10 * float(heur.abs().max()), rtol=1e-9)
+
+
+def test_reference_tail_order_known_answers():
+  # forward.py:86-89: group g visits min(group, count - g) entries; beyond the valid ones it re-reads what the
+  # previous group left in shared memory
+  assert orast.reference_tail_order(5, 256) == list(range(5))
+  assert orast.reference_tail_order(256, 256) == list(range(256))
+  order = orast.reference_tail_order(300, 256)
+  assert order[:300] == list(range(300))
+  assert order[300:] == list(range(44, 256))            # stale entries 44..255 of group 0, blended a second time
+  assert len(order) == 256 + min(256, 300 - 1)
+  order = orast.reference_tail_order(130, 64)           # backward block of 64 threads (tile 16, stride 2x2)
+  assert order[:130] == list(range(130)) and order[130:] == list(range(64 + 2, 128))
+
+
+def test_reference_loop_bound_emulation_changes_only_unsaturated_tails():
+  torch.manual_seed(2)
+  size = (16, 16)
+  g = random_2d_gaussians(300, size, scale_factor=3.0, alpha_range=(0.02, 0.2))
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, 16)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  assert int(ranges.reshape(-1, 2)[0, 1]) > 256
+  cfg = orast.Cfg()
+  img, alpha, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  img_r, alpha_r, _ = orast.forward(p, f, ranges, o2p, size, cfg, emulate_reference_loop_bound=True)
+  assert bool((alpha_r >= alpha - 1e-15).all()) and float((alpha_r - alpha).max()) > 1e-3   # re-blended tail adds weight
+  # opaque front layer: nothing is left to re-blend, both orders give the same image
+  p2 = p.clone(); p2[:, 6] = 0.995; p2[:, 4:6] = 30.0
+  img2, alpha2, _ = orast.forward(p2, f, ranges, o2p, size, cfg)
+  img2_r, alpha2_r, _ = orast.forward(p2, f, ranges, o2p, size, cfg, emulate_reference_loop_bound=True)
+  assert torch.allclose(img2, img2_r, atol=1e-9) and torch.allclose(alpha2, alpha2_r, atol=1e-9)
+  # <= 256 splats per tile: the defect cannot trigger
+  few = o2p[:200]
+  r_few = torch.tensor([[0, 200]], dtype=torch.int32)
+  a, _, _ = orast.forward(p, f, r_few, few, size, cfg)
+  b, _, _ = orast.forward(p, f, r_few, few, size, cfg, emulate_reference_loop_bound=True)
+  assert torch.equal(a, b)
+
+
+def test_gate_margin_matches_borderline_pixels():
+  torch.manual_seed(9)
+  size = (48, 32)
+  g = random_2d_gaussians(600, size, scale_factor=1.5)
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, 16)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  cfg = orast.Cfg()
+  margin = orast.gate_margin(p, ranges, o2p, size, cfg)
+  listed = torch.zeros(600, dtype=torch.bool); listed[o2p.long()] = True
+  assert bool(torch.isfinite(margin[listed]).all()) and bool(torch.isinf(margin[~listed]).all())
+  # dropping every splat closer than 1e-3 to the gate leaves a scene without borderline pixels at 1e-6
+  keep = margin > 1e-3
+  assert 0.5 < keep.float().mean() < 1.0
+  p2, f2, d2 = p[keep], f[keep], g.depths[keep]
+  o2p2, ranges2, _ = omap.map_to_tiles(p2.numpy(), d2.numpy(), size, 16)
+  _, _, _, border = orast.forward(p2, f2, torch.from_numpy(ranges2), torch.from_numpy(o2p2), size, cfg, return_borderline=True)
+  assert not bool(border.any())
+
+
+def test_non_blending_mode_accumulates_visibility():
+  # forward.py:114-126: the blend weights keep flowing into `visibility` with use_alpha_blending=False
+  torch.manual_seed(4)
+  size = (16, 16)
+  g = random_2d_gaussians(60, size, scale_factor=2.0, alpha_range=(0.1, 0.5))
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, 16)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  _, _, vis_blend = orast.forward(p, f, ranges, o2p, size, orast.Cfg())
+  _, _, vis_median = orast.forward(p, f, ranges, o2p, size, orast.Cfg(use_alpha_blending=False, saturate_threshold=0.25))
+  assert float(vis_blend.sum()) > 0 and torch.allclose(vis_blend, vis_median)

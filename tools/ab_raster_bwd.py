@@ -43,7 +43,7 @@ def main():
       size = (1024, 768)
       g = random_2d_gaussians(1_000_000, size, num_channels=3, scale_factor=4.0, alpha_range=(0.75, 1.0),
                               depth_range=(0.1, 100.0)).to(dev)
-      g2d, feats, depth = project_gaussians2d(g), g.feature.contiguous(), g.z_depth.contiguous()
+      g2d, feats, depth = project_gaussians2d(g), g.feature.contiguous(), g.depths.contiguous()
       o2p, ranges = map_to_tiles(g2d, depth, size, cfg)
       w, h = size
     else:
