@@ -144,9 +144,12 @@ fractional_update_kernel(UpdateArgs a) {
     g[0] = sub < d ? gl : 0.f;
   }
 
-  const float b1w = exp2f(w * a.log2_beta1), b2w = exp2f(w * a.log2_beta2);
-  const float bias1 = a.bias_correction ? 1.0f - exp2f(tw * a.log2_beta1) : 1.0f;
-  const float bias2 = a.bias_correction ? 1.0f - exp2f(tw * a.log2_beta2) : 1.0f;
+  // beta^w with beta^0 = 1 also for beta = 0 (log2 beta = -inf would give 0 * -inf = NaN and poison the
+  // persistent moments of a point with zero weight, e.g. zero visibility; the reference's beta ** w gives 1)
+  auto pow_beta = [](float e, float log2_beta) { return e == 0.0f ? 1.0f : exp2f(e * log2_beta); };
+  const float b1w = pow_beta(w, a.log2_beta1), b2w = pow_beta(w, a.log2_beta2);
+  const float bias1 = a.bias_correction ? 1.0f - pow_beta(tw, a.log2_beta1) : 1.0f;
+  const float bias2 = a.bias_correction ? 1.0f - pow_beta(tw, a.log2_beta2) : 1.0f;
 
   float step[KMAX];
   if (TYPE != 0) {

@@ -69,6 +69,16 @@ __device__ __forceinline__ float wave_scan_mul(float v) { MS_SCAN_ASM("v_mul_f32
 __device__ __forceinline__ float wave_scan_add(float v) { MS_SCAN_ASM("v_add_f32_dpp"); return v; }
 #undef MS_SCAN_ASM
 
+// Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows, the pixel state written by
+// the last lane).  LDS operations of a wave execute in order, but the COMPILER reasons per thread: without a
+// fence it may keep a value this thread loaded earlier instead of re-reading what another lane stored (observed:
+// the <R, G> state was forwarded from registers).  Release + acquire at wavefront scope costs no instruction.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 // 48-byte LDS record of a staged splat:
@@ -170,6 +180,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
+    wave_lds_fence();
     if (__syncthreads_and(__float_as_uint(s_pix[wave][lane].w) <= oms_bits)) break;
 
     if (PIPELINED) {
@@ -227,8 +238,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         pcount += nany;
         r += 64;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
 #if MS_SCAN_ABLATE == 1
       continue;
 #endif
@@ -245,6 +255,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       for (int q = 0; q < 4; ++q) {
         const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
         if (n == 0) continue;
+        wave_lds_fence();
         const unsigned long long alive = __ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits);
         if (((alive >> (16 * q)) & 0xffffull) == 0) continue;
         const int pbase = q * 16;
@@ -252,6 +263,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
 #pragma unroll 1
         for (int c0 = 0; c0 < n; c0 += 64) {
+          wave_lds_fence();                      // pixel state and accumulator rows written by other lanes in earlier chunks
           const bool valid = c0 + lane < n;
           const int pos = valid ? (int)s_list[wave][q][c0 + lane] : 0;
           const int idx = (int)s_plist[wave][pos];
@@ -338,8 +350,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       }
 
       // ---- commit the pass: ONE 64-byte row of global float atomics per (patch, splat), 16 lanes per row -----
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
       for (int i = lane; i < pcount * MOMENT_ROW; i += 64) {
         const int e = i >> 4, k = i & 15;
         if (k < NACC) {
@@ -350,8 +361,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      wave_lds_fence();
     }
   }
 }

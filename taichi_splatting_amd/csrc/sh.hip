@@ -64,8 +64,10 @@ sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
 #pragma unroll
       for (int d = 0; d < D; ++d) acc += Y[d] * p[c * D + d];
       const T pre = acc + T(0.5);
-      // clamp passes the gradient where 0 <= pre <= 1 (torch.clamp convention)
-      const T g = (pre >= T(0) && pre <= T(1)) ? g_out[i * f + c] : T(0);
+      // the clamp passes the gradient strictly inside (0, 1): the convention of Taichi's min / max autodiff
+      // (indexed_spherical_harmonics.py:133,158) and the only one sh_bwd_params_kernel can apply, which sees the
+      // clamped output; both kernels must agree or d(params) and d(direction) of one point would disagree
+      const T g = (pre > T(0) && pre < T(1)) ? g_out[i * f + c] : T(0);
       if (g_params) {
         T* gp = g_params + (idx * (int64_t)f + c) * D;
 #pragma unroll

@@ -1,0 +1,230 @@
+"""-m gpu: BASELINE.json configs C (1 M gaussians, 1920x1080, SH degree 3, forward + backward) and E's frame on
+one GPU (6 M gaussians, 4096x4096: 65 536 tiles at tile 16, and tile 32).
+
+Each configuration is checked twice:
+  * oracle parity on a SAME-ASPECT, SAME-DENSITY down-scale the CPU oracle finishes in seconds (the generator
+    sizes gaussians as width / sqrt(n) pixels, so n / pixels fixed keeps the per-tile population), float32, on
+    a GATE-STABLE scene: gaussians with a (pixel, splat) pair closer than 1e-4 (relative) to the blend gate
+    alpha > alpha_threshold are removed first (oracle.raster.gate_margin), so no float32 rounding can flip a
+    gate and pixels AND gradients must agree to the 1e-4 of BASELINE.json's north_star everywhere, with no
+    quantile or absolute slack;
+  * at full size through size-independent properties: mapper invariants, the float32 product kernels against
+    the float64 generic kernels on the same tile lists, tile-row strips composing to the full frame in image and
+    in gradient, finite gradients."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mapper as omap, projection as oproj, raster as orast, sh as osh
+from taichi_splatting_amd import RasterConfig, map_to_tiles, rasterize_with_tiles, render_gaussians
+from taichi_splatting_amd.perspective.projection import project_to_image
+from taichi_splatting_amd.rendering import ndc_depth
+from taichi_splatting_amd.spherical_harmonics import evaluate_sh_at
+from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+LEAVES = ('position', 'log_scaling', 'rotation', 'alpha_logit', 'feature')
+
+
+def scene(n, size, seed=0, sh_degree=3):
+  torch.manual_seed(seed)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9), margin=0.0)
+  g = g.replace(feature=(torch.rand(n, 3, (sh_degree + 1) ** 2) - 0.5) * 0.5)
+  return g, cam
+
+
+def cfg_for(tile):
+  return RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
+
+
+def oracle_frame(g, cam, cfg, G):
+  """float64 oracle pipeline with gradients of sum(image * G) for the five leaves."""
+  g, cam = g.to(dtype=torch.float64), cam.to(dtype=torch.float64)
+  leaves = [getattr(g, k).detach().clone().requires_grad_(True) for k in LEAVES]
+  pos, ls, rot, al, feat = leaves
+  points, depths, idx = oproj.apply(pos, ls, rot, al, cam.T_camera_world, cam.projection, cam.image_size,
+                                    cam.depth_range, cfg.blur_cov, cfg.clamp_margin, cfg.alpha_threshold)
+  feats = osh.evaluate_sh_at(feat, pos.detach(), idx, torch.inverse(cam.T_camera_world)[0:3, 3])
+  ndc = oproj.ndc_depth(depths.detach(), *cam.depth_range)
+  o2p, ranges, _ = omap.map_to_tiles(points.detach().numpy().astype(np.float32), ndc.numpy().astype(np.float32),
+                                     cam.image_size, cfg.tile_size, cfg.alpha_threshold)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  out = dict(points=points.detach(), feats=feats.detach(), idx=idx, o2p=o2p, ranges=ranges)
+  if G is None:
+    return out
+  image, alpha, _ = orast.forward(points.detach(), feats.detach(), ranges, o2p, cam.image_size, cfg)
+  gp, gf, _ = orast.backward(points.detach(), feats.detach(), ranges, o2p, image, G, cam.image_size, cfg)
+  torch.autograd.backward([points, feats], [gp, gf])
+  out.update(image=image, alpha=alpha, grads=[x.grad for x in leaves], grad_points=gp, grad_feats=gf)
+  return out
+
+
+def gate_stable(g, cam, cfg, rel_margin=1e-4):
+  """Drop the gaussians whose projected splat has a pixel within ``rel_margin`` of the blend gate."""
+  o = oracle_frame(g, cam, cfg, None)
+  margin = orast.gate_margin(o['points'], o['ranges'], o['o2p'], cam.image_size, cfg)
+  keep = torch.ones(g.position.shape[0], dtype=torch.bool)
+  keep[o['idx'][margin < rel_margin]] = False
+  assert keep.float().mean() > 0.8
+  return g[keep]
+
+
+@pytest.mark.parametrize('name,n,size,tile', [
+  ('C/8', 15_625, (240, 135), 16),          # config C at 1/8 scale: 1920x1080 -> 240x135 (135 is not a tile multiple)
+  ('C/8 tile 8', 15_625, (240, 135), 8),
+  ('E/32', 5_860, (128, 128), 16),           # config E at 1/32 scale: 4096^2 -> 128^2, 6 M -> 5 860 (same density)
+  ('D/16 tile 32', 23_437, (128, 128), 32),  # config D at 1/16 scale
+])
+def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
+  cfg = cfg_for(tile)
+  g, cam = scene(n, size, seed=1)
+  g = gate_stable(g, cam, cfg)
+  torch.manual_seed(2)
+  G = torch.rand(size[1], size[0], 3, dtype=torch.float64) + 0.5
+  want = oracle_frame(g, cam, cfg, G)
+
+  gd = g.to(DEV).requires_grad_(True)
+  r = render_gaussians(gd, cam.to(device=DEV), cfg, use_sh=True)
+  assert torch.equal(r.points.idx.cpu(), want['idx'])                       # same visible set
+  err = (r.image.cpu().double() - want['image']).abs()
+  assert err.max() < 1e-4, (name, err.max())                                # every pixel, no borderline mask
+  assert (r.image_weight.cpu().double() - want['alpha']).abs().max() < 1e-4
+  (r.image * G.to(DEV).float()).sum().backward()
+  for k, w in zip(LEAVES, want['grads']):
+    got = getattr(gd, k).grad.cpu().double()
+    scale = w.abs().max().item()
+    assert (got - w).abs().max() < 1e-4 * scale, (name, k, (got - w).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('tile', [8, 16, 32])
+def test_raster_f32_gradients_strict_on_gate_stable_scene(tile):
+  """The rasterizer alone (2D boundary): float32 kernels vs the float64 oracle, gradients within 1e-4 of the
+  largest gradient for EVERY splat — the tolerance north_star states, without the absolute slack and quantile
+  the round-1 assertions needed for scenes that contain borderline gates."""
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  size = (256, 256)
+  cfg = cfg_for(tile)
+  torch.manual_seed(tile)
+  g = random_2d_gaussians(10000, size, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  p, f, d = project_gaussians2d(g).double(), g.feature.double(), g.depths
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), d.numpy(), size, tile)
+  margin = orast.gate_margin(p, torch.from_numpy(ranges), torch.from_numpy(o2p), size, cfg)
+  keep = margin > 1e-4
+  p, f, d = p[keep], f[keep], d[keep]
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), d.numpy(), size, tile)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  cfg_h = RasterConfig(tile_size=tile, pixel_stride=cfg.pixel_stride, compute_point_heuristic=True)
+  img, alpha, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  G = torch.rand_like(img) + 0.5
+  gp, gf, heur = orast.backward(p, f, ranges, o2p, img, G, size, cfg_h)
+
+  pg, fg = p.float().to(DEV).requires_grad_(True), f.float().to(DEV).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg_h)
+  assert (out.image.cpu().double() - img).abs().max() < 1e-4
+  assert (out.image_weight.cpu().double() - alpha).abs().max() < 1e-4
+  (out.image * G.to(DEV).float()).sum().backward()
+  for name, got, want in (('gaussians2d', pg.grad, gp), ('features', fg.grad, gf), ('heuristic', out.point_heuristic, heur)):
+    scale = want.abs().max().item()
+    assert (got.cpu().double() - want).abs().max() < 1e-4 * scale, (name, (got.cpu().double() - want).abs().max().item(), scale)
+
+
+def mapper_invariants(p, nd, o2p, ranges):
+  K = o2p.shape[0]
+  flat = ranges.view(-1, 2).long()
+  counts = flat[:, 1] - flat[:, 0]
+  assert int(counts.sum()) == K and int(counts.min()) >= 0
+  ne = flat[counts > 0]
+  ne = ne[torch.argsort(ne[:, 0])]
+  assert int(ne[0, 0]) == 0 and int(ne[-1, 1]) == K and torch.equal(ne[1:, 0], ne[:-1, 1])   # partition of [0, K)
+  assert int(o2p.min()) >= 0 and int(o2p.max()) < p.shape[0]
+  d = nd.view(-1)[o2p.long()]
+  tile_of = torch.repeat_interleave(torch.arange(flat.shape[0], device=p.device), counts)
+  same = tile_of[1:] == tile_of[:-1]
+  assert bool(((d[1:] >= d[:-1]) | ~same).all())                            # depth sorted inside every tile
+  ties = same & (d[1:] == d[:-1])
+  assert bool(((o2p[1:] > o2p[:-1]) | ~ties).all())                         # ties by ascending point index
+  return counts
+
+
+def strips_compose(g, cam, cfg, bounds, full_image, full_grads):
+  """Render the frame strip by strip (what each rank of the multi-GPU decomposition does): the strip images tile
+  the full image exactly, the strip gradients add up to the full-frame gradients."""
+  ts, h = cfg.tile_size, cam.image_size[1]
+  for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature):
+    t.grad = None
+  for b0, b1 in zip(bounds[:-1], bounds[1:]):
+    r = render_gaussians(g, cam, cfg, use_sh=True, tile_rows=(b0, b1))
+    y0, y1 = min(b0 * ts, h), min(b1 * ts, h)
+    assert torch.equal(r.image[y0:y1], full_image[y0:y1])
+    assert float(r.image[:y0].abs().sum()) == 0 and float(r.image[y1:].abs().sum()) == 0
+    r.image.sum().backward()
+  for k, want in zip(LEAVES, full_grads):
+    got = getattr(g, k).grad
+    assert torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max() < 1e-4 * scale, (k, (got - want).abs().max().item(), scale)
+
+
+def full_frame(g, cam, cfg):
+  g.requires_grad_(True)
+  r = render_gaussians(g, cam, cfg, use_sh=True)
+  r.image.sum().backward()
+  grads = [getattr(g, k).grad.clone() for k in LEAVES]
+  for gr in grads:
+    assert torch.isfinite(gr).all()
+  return r, grads
+
+
+def test_config_c_full_size():
+  """1 M gaussians, 1920x1080 (67.5 tile rows), SH degree 3, forward + backward."""
+  g, cam = scene(1_000_000, (1920, 1080))
+  g, cam, cfg = g.to(DEV), cam.to(device=DEV), cfg_for(16)
+  with torch.no_grad():
+    p, depth, idx = project_to_image(g, cam, cfg)
+    nd = ndc_depth(depth, cam.near_plane, cam.far_plane)
+    o2p, ranges = map_to_tiles(p, nd, cam.image_size, cfg)
+    feats = evaluate_sh_at(g.feature, g.position, idx, cam.camera_position)
+  assert ranges.shape[:2] == (68, 120) and idx.shape[0] == 1_000_000
+  mapper_invariants(p, nd, o2p, ranges)
+
+  # float32 product kernels vs float64 generic kernels on the same tile lists, forward and backward
+  torch.manual_seed(3)
+  G = torch.rand(1080, 1920, 3, device=DEV) + 0.5
+  res = {}
+  for dtype in (torch.float64, torch.float32):
+    pp, ff = p.to(dtype).requires_grad_(True), feats.to(dtype).requires_grad_(True)
+    out = rasterize_with_tiles(pp, ff, o2p, ranges.view(-1, 2), cam.image_size, cfg)
+    (out.image * G.to(dtype)).sum().backward()
+    res[dtype] = (out.image.detach().double(), pp.grad.double(), ff.grad.double())
+  err = (res[torch.float32][0] - res[torch.float64][0]).abs().max(-1).values
+  assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2                   # gates may flip in f32 here (not gate-stable)
+  for got, want in zip(res[torch.float32][1:], res[torch.float64][1:]):
+    scale = want.abs().max().item()
+    rel = (got - want).abs() / (want.abs() + 1e-3 * scale)
+    assert rel.flatten()[:8_000_000].quantile(0.999) < 2e-3 and (got - want).abs().max() < 2e-2 * scale
+
+  r, grads = full_frame(g, cam, cfg)
+  assert r.image.shape == (1080, 1920, 3) and float(r.image.min()) >= 0
+  strips_compose(g, cam, cfg, [0, 17, 34, 51, 68], r.image.detach(), grads)
+
+
+@pytest.mark.parametrize('tile', [16, 32])
+def test_config_e_frame_on_one_gpu(tile):
+  """6 M gaussians, 4096x4096: 65 536 tiles at tile 16 (the reference asserts tiles < 65 535,
+  mapper/tile_mapper.py:177-178), strips as the 8-GPU decomposition cuts them."""
+  g, cam = scene(6_000_000, (4096, 4096))
+  g, cam, cfg = g.to(DEV), cam.to(device=DEV), cfg_for(tile)
+  with torch.no_grad():
+    p, depth, idx = project_to_image(g, cam, cfg)
+    nd = ndc_depth(depth, cam.near_plane, cam.far_plane)
+    o2p, ranges = map_to_tiles(p, nd, cam.image_size, cfg)
+  th = 4096 // tile
+  assert ranges.shape[:2] == (th, th) and idx.shape[0] == 6_000_000
+  mapper_invariants(p, nd, o2p, ranges)
+  del p, depth, nd, o2p, ranges
+  r, grads = full_frame(g, cam, cfg)
+  assert float(r.image_weight.max()) <= 1.0 + 1e-5
+  strips_compose(g, cam, cfg, [(th * k) // 8 for k in range(9)], r.image.detach(), grads)
