@@ -27,7 +27,10 @@
 
 namespace ms {
 
-constexpr int RASTER_MAX_F = 4;
+constexpr int RASTER_MAX_F = 4;          // forward, and backward without point heuristics: wider features are chunked on the host
+constexpr int RASTER_MAX_F_HEUR = 16;    // backward WITH point heuristics: F = 8 and 16 are instantiated too (see ms_raster_bwd)
+// number of per-pixel gradient values a backward pass reduces per splat, padded to the butterfly's 16 slots
+template <int F> struct GradSlots { static constexpr int N = F <= 4 ? 16 : 7 + F + 2; };
 
 template <typename T> struct RasterParams {
   int width, height, tiles_wide, tile_begin;   // tile_begin = first tile id of the strip
@@ -297,9 +300,21 @@ __device__ __forceinline__ void grad_target(int lane, T* grad_points, T* grad_fe
   else if (HEUR && k < 7 + F + 2) { if (heuristic) { base = heuristic + (k - 7 - F); stride = 2; } }
 }
 
+// General form (double, and float with more than 4 channels): one tree reduction + one atomic per value.
+// The float instantiations for F <= 4 — everything the product path launches — are specialised below with the
+// halving butterfly (one atomic instruction per splat).
 template <typename T, int F, bool HEUR>
-__device__ __forceinline__ void commit_gradients(const T (&v)[16], int32_t id, int lane, T* tgt_base,
-                                                 int tgt_stride, T* grad_points, T* grad_feats, T* heuristic);
+__device__ __forceinline__ void commit_gradients(const T (&v)[GradSlots<F>::N], int32_t id, int lane, T* tgt_base,
+                                                 int tgt_stride, T* gp, T* gf, T* heur) {
+  for (int k = 0; k < 7 + F + (HEUR ? 2 : 0); ++k) {
+    const T total = wave_sum_to_lane63(v[k]);
+    if (lane == 63) {
+      if (k < 7) { if (gp) atomic_add_noret(gp + (int64_t)id * 7 + k, total); }
+      else if (k < 7 + F) { if (gf) atomic_add_noret(gf + (int64_t)id * F + (k - 7), total); }
+      else if (heur) atomic_add_noret(heur + (int64_t)id * 2 + (k - 7 - F), total);
+    }
+  }
+}
 
 template <>
 __device__ __forceinline__ void commit_gradients<float, 1, false>(const float (&v)[16], int32_t id, int lane, float* b, int st, float*, float*, float*) {
@@ -317,25 +332,6 @@ MS_COMMIT_F32(1, true) MS_COMMIT_F32(2, false) MS_COMMIT_F32(2, true) MS_COMMIT_
 MS_COMMIT_F32(3, true) MS_COMMIT_F32(4, false) MS_COMMIT_F32(4, true)
 #undef MS_COMMIT_F32
 
-// double: test-only path, one tree reduction + one atomic per value
-#define MS_COMMIT_F64(F, HEUR)                                                                                   \
-  template <>                                                                                                    \
-  __device__ __forceinline__ void commit_gradients<double, F, HEUR>(const double (&v)[16], int32_t id, int lane, \
-                                                                    double*, int, double* gp, double* gf,        \
-                                                                    double* heur) {                              \
-    for (int k = 0; k < 7 + F + (HEUR ? 2 : 0); ++k) {                                                           \
-      const double total = wave_sum_to_lane63(v[k]);                                                             \
-      if (lane == 63) {                                                                                          \
-        if (k < 7) { if (gp) atomic_add_noret(gp + (int64_t)id * 7 + k, total); }                                \
-        else if (k < 7 + F) { if (gf) atomic_add_noret(gf + (int64_t)id * F + (k - 7), total); }                 \
-        else if (heur) atomic_add_noret(heur + (int64_t)id * 2 + (k - 7 - F), total);                            \
-      }                                                                                                          \
-    }                                                                                                            \
-  }
-MS_COMMIT_F64(1, false) MS_COMMIT_F64(1, true) MS_COMMIT_F64(2, false) MS_COMMIT_F64(2, true)
-MS_COMMIT_F64(3, false) MS_COMMIT_F64(3, true) MS_COMMIT_F64(4, false) MS_COMMIT_F64(4, true)
-#undef MS_COMMIT_F64
-
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -346,7 +342,8 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
                   const T* __restrict__ image, const T* __restrict__ grad_image, RasterParams<T> rp,
                   T* __restrict__ grad_points, T* __restrict__ grad_feats, T* __restrict__ heuristic) {
   constexpr int THREADS = TS * TS;
-  constexpr int BATCH = THREADS < 256 ? THREADS : 256;
+  constexpr int BATCH_MAX = F > 4 ? 128 : 256;       // wide records: keep the staging arrays inside 64 KB of LDS
+  constexpr int BATCH = THREADS < BATCH_MAX ? THREADS : BATCH_MAX;
   constexpr int WAVES_WIDE = TS / 8;
 
   __shared__ Splat<T, F> s_splat[BATCH];
@@ -441,7 +438,7 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
         if (__ballot(active) == 0) continue;     // no pixel of this patch contributes
 
         constexpr int NV = 7 + F + (HEUR ? 2 : 0);
-        T v[16];
+        T v[GradSlots<F>::N];
         v[0] = aag * gm[0]; v[1] = aag * gm[1];
         v[2] = aag * ga[0]; v[3] = aag * ga[1];
         v[4] = aag * gs[0]; v[5] = aag * gs[1];
@@ -453,7 +450,7 @@ raster_bwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
           v[7 + F + 1] = t_abs(v[0]) + t_abs(v[1]);
         }
 #pragma unroll
-        for (int k = NV; k < 16; ++k) v[k] = T(0);
+        for (int k = NV; k < GradSlots<F>::N; ++k) v[k] = T(0);
 
         const int32_t id = s_id[r + b];
         commit_gradients<T, F, HEUR>(v, id, lane, tgt_base, tgt_stride, grad_points, grad_feats, heuristic);
@@ -519,6 +516,32 @@ static int dispatch_ts_fwd(int ts, Args... args) {
   return MS_ERR_UNSUPPORTED;
 }
 
+// F = 8 / 16: backward with point heuristics only (prune_cost and split_score are not linear in the channels, so
+// they cannot be assembled from 4-channel chunks: backward.py:171-194 forms alpha_grad over ALL channels first)
+template <typename T, int F, int TS>
+static void launch_bwd_wide(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
+                            const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
+                            void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s) {
+  const RasterParams<T> rp = make_raster_params<T>(w, h, cfg, row_begin);
+  const dim3 grid((unsigned)num_tiles), block(TS * TS);
+  if (cfg->antialias)
+    raster_bwd_kernel<T, F, TS, true, true><<<grid, block, 0, s>>>((const T*)points, (const T*)feats, ranges, o2p, (const T*)image,
+                                                                   (const T*)grad_image, rp, (T*)gp, (T*)gf, (T*)heur);
+  else
+    raster_bwd_kernel<T, F, TS, false, true><<<grid, block, 0, s>>>((const T*)points, (const T*)feats, ranges, o2p, (const T*)image,
+                                                                    (const T*)grad_image, rp, (T*)gp, (T*)gf, (T*)heur);
+}
+
+template <typename T, int F, typename... Args>
+static int dispatch_ts_bwd_wide(int ts, Args... args) {
+  switch (ts) {
+    case 8: launch_bwd_wide<T, F, 8>(args...); return 0;
+    case 16: launch_bwd_wide<T, F, 16>(args...); return 0;
+    case 32: launch_bwd_wide<T, F, 32>(args...); return 0;
+  }
+  return MS_ERR_UNSUPPORTED;
+}
+
 template <typename T, int F, typename... Args>
 static int dispatch_ts_bwd(int ts, Args... args) {
   switch (ts) {
@@ -542,15 +565,16 @@ bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ra
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
 
 static int check_raster_common(const ms_raster_config* cfg, int w, int h, int f, int dtype, int* row_begin,
-                               int* row_end, const char* fn) {
+                               int* row_end, const char* fn, int max_f = RASTER_MAX_F) {
   if (!cfg) { set_error("%s: cfg is null", fn); return MS_ERR_BAD_ARG; }
   if (w <= 0 || h <= 0) { set_error("%s: bad image size %dx%d", fn, w, h); return MS_ERR_BAD_ARG; }
   if (dtype != MS_F32 && dtype != MS_F64) { set_error("%s: dtype must be MS_F32 or MS_F64", fn); return MS_ERR_BAD_ARG; }
   if (cfg->tile_size != 8 && cfg->tile_size != 16 && cfg->tile_size != 32) {
     set_error("%s: tile_size must be 8, 16 or 32 (got %d)", fn, cfg->tile_size); return MS_ERR_UNSUPPORTED;
   }
-  if (f < 1 || f > RASTER_MAX_F) {
-    set_error("%s: feature size %d not in [1, %d] (split the channels on the host)", fn, f, RASTER_MAX_F);
+  if (f < 1 || f > max_f || (f > RASTER_MAX_F && f != 8 && f != 16)) {
+    set_error("%s: feature size %d not supported: 1..%d, or 8 / 16 for the backward pass with point heuristics "
+              "(split or zero-pad the channels on the host)", fn, f, RASTER_MAX_F);
     return MS_ERR_UNSUPPORTED;
   }
   const int tiles_high = (h + cfg->tile_size - 1) / cfg->tile_size;
@@ -596,7 +620,9 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
                              int image_w, int image_h, int f, const ms_raster_config* cfg,
                              void* grad_points7, void* grad_features, void* point_heuristic,
                              int tile_row_begin, int tile_row_end, int dtype, void* stream) {
-  int rc = check_raster_common(cfg, image_w, image_h, f, dtype, &tile_row_begin, &tile_row_end, "ms_raster_bwd");
+  const bool wide = cfg && cfg->compute_point_heuristic && point_heuristic;
+  int rc = check_raster_common(cfg, image_w, image_h, f, dtype, &tile_row_begin, &tile_row_end, "ms_raster_bwd",
+                               wide ? RASTER_MAX_F_HEUR : RASTER_MAX_F);
   if (rc) return rc;
   MS_CHECK_ARG(tile_ranges && image && grad_image, "null pointer");
   MS_CHECK_ARG(cfg->use_alpha_blending, "backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)");
@@ -611,6 +637,15 @@ extern "C" int ms_raster_bwd(const void* points7, const void* features, const in
       MS_CHECK_LAUNCH();
       return 0;
     }
+  }
+  if (f > RASTER_MAX_F) {
+#define MS_WIDE(T, F) rc = dispatch_ts_bwd_wide<T, F>(cfg->tile_size, points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)
+    if (dtype == MS_F32) { if (f == 8) MS_WIDE(float, 8); else MS_WIDE(float, 16); }
+    else { if (f == 8) MS_WIDE(double, 8); else MS_WIDE(double, 16); }
+#undef MS_WIDE
+    if (rc) return rc;
+    MS_CHECK_LAUNCH();
+    return 0;
   }
 #define MS_GO(T, F) rc = dispatch_ts_bwd<T, F>(cfg->tile_size, points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg, grad_points7, grad_features, point_heuristic, tile_row_begin, num_tiles, s)
   if (dtype == MS_F32) {

@@ -23,6 +23,7 @@ RasterOut = NamedTuple('RasterOut', [
 ])
 
 MAX_KERNEL_FEATURES = 4   # csrc/raster.hip instantiates F = 1..4; wider features are chunked
+WIDE_KERNEL_FEATURES = (8, 16)   # backward with point heuristics: instantiated too (zero-padded up to these widths)
 
 
 def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
@@ -94,6 +95,15 @@ class _RasterFunction(torch.autograd.Function):
     stream = _lib.current_stream(device)
     cfg_c = _lib.raster_config_c(config)
 
+    if config.compute_visibility and not config.use_alpha_blending:
+      # forward.py:114-126 keeps summing blend weights into `visibility` in quantile mode until all 32 lanes of a
+      # CUDA warp are saturated (forward.py:92-94): the result depends on the reference's thread -> pixel map and
+      # is not reproduced here.  render_gaussians disables visibility for its median pass (renderer.py:80).
+      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
+                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
+    if config.compute_point_heuristic and f > WIDE_KERNEL_FEATURES[-1]:
+      raise NotImplementedError(f"compute_point_heuristic with {f} > {WIDE_KERNEL_FEATURES[-1]} feature channels: "
+                                "prune_cost / split_score need dL/dalpha over ALL channels at once")
     if config.compute_point_heuristic:
       point_heuristic = torch.zeros((n, 2), dtype=dtype, device=device)
     else:
@@ -165,6 +175,21 @@ class _RasterFunction(torch.autograd.Function):
       _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), n, _lib.ptr(grad_gaussians),
                                                 _lib.ptr(grad_features), _lib.ptr(heuristic), stream),
                  "rasterize backward (moments -> gradients)")
+    elif f > MAX_KERNEL_FEATURES and heuristic is not None:
+      # the heuristics square / take |.| of dL/dalpha summed over ALL channels (backward.py:171-194), so the
+      # channels cannot be split: one launch of the F = 8 / 16 instantiation on zero-padded channels (a channel
+      # whose dL/dimage is zero contributes nothing)
+      fw = next(k for k in WIDE_KERNEL_FEATURES if k >= f)
+      pad = lambda t: torch.nn.functional.pad(t, (0, fw - f)).contiguous()
+      feat_w, img_w, gimg_w = pad(features), pad(image), pad(grad_image)
+      gfeat_w = torch.zeros_like(feat_w) if need_features else None
+      _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), feat_w.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
+                                   _lib.ptr(ctx.overlap_to_point), img_w.data_ptr() - row_bytes * fw,
+                                   gimg_w.data_ptr() - row_bytes * fw, w, h, fw, cfg_c, _lib.ptr(grad_gaussians),
+                                   _lib.ptr(gfeat_w), _lib.ptr(heuristic), ctx.rows[0], ctx.rows[1], dtype_code, stream),
+                 "rasterize backward")
+      if need_features:
+        grad_features.copy_(gfeat_w[:, :f])
     elif f <= MAX_KERNEL_FEATURES:
       _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                    _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
@@ -173,7 +198,7 @@ class _RasterFunction(torch.autograd.Function):
                  "rasterize backward")
     else:
       # d(alpha) = sum_c (...)_c * G_c is linear in the channels, so point gradients of channel
-      # chunks add up exactly; the heuristics are not linear and use the first chunk only.
+      # chunks add up exactly (no heuristics on this path: see above).
       for c0 in range(0, f, MAX_KERNEL_FEATURES):
         sl = slice(c0, c0 + MAX_KERNEL_FEATURES)
         feat_c = features[:, sl].contiguous()
@@ -183,7 +208,7 @@ class _RasterFunction(torch.autograd.Function):
         _lib.check(lib.ms_raster_bwd(gaussians.data_ptr(), feat_c.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                      _lib.ptr(ctx.overlap_to_point), img_c.data_ptr() - row_bytes * feat_c.shape[1],
                                      gimg_c.data_ptr() - row_bytes * feat_c.shape[1], w, h, feat_c.shape[1], cfg_c, _lib.ptr(grad_gaussians), _lib.ptr(gfeat_c),
-                                     _lib.ptr(heuristic) if c0 == 0 else None, ctx.rows[0], ctx.rows[1],
+                                     None, ctx.rows[0], ctx.rows[1],
                                      dtype_code, stream), "rasterize backward")
         if need_features:
           grad_features[:, sl] = gfeat_c

@@ -147,6 +147,38 @@ def test_feature_widths(channels):
   assert torch.allclose(fg.grad.cpu(), gf_o, atol=1e-9)
 
 
+@pytest.mark.parametrize('channels,dtype', [(5, torch.float64), (9, torch.float64), (16, torch.float64), (7, torch.float32)])
+def test_point_heuristics_with_wide_features(channels, dtype):
+  # prune_cost / split_score square and take |.| of dL/dalpha summed over ALL channels (backward.py:171-194):
+  # with more than 4 channels they must not be assembled from channel chunks
+  size = (96, 64)
+  cfg = RasterConfig(compute_point_heuristic=True)
+  p, f, d, o2p, ranges = scene(1500, size, seed=channels, channels=channels)
+  p, f = p.double(), f.double()
+  img_o, a_o, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  torch.manual_seed(3)
+  G = torch.randn_like(img_o)
+  gp_o, gf_o, h_o = orast.backward(p, f, ranges, o2p, img_o, G, size, cfg)
+  pg, fg = p.to(DEV, dtype).requires_grad_(True), f.to(DEV, dtype).requires_grad_(True)
+  out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  (out.image * G.to(DEV, dtype)).sum().backward()
+  tol = 1e-8 if dtype == torch.float64 else 1e-4
+  for got, want in ((pg.grad, gp_o), (fg.grad, gf_o), (out.point_heuristic, h_o)):
+    scale = max(1.0, want.abs().max().item())
+    assert (got.cpu().double() - want).abs().max() < tol * scale, ((got.cpu().double() - want).abs().max(), scale)
+  with pytest.raises(NotImplementedError):
+    wide = torch.zeros((p.shape[0], 17), device=DEV, dtype=dtype)
+    rasterize_with_tiles(pg.detach(), wide, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+
+
+def test_quantile_mode_rejects_visibility():
+  size = (32, 32)
+  p, f, d, o2p, ranges = scene(100, size, seed=1, channels=1)
+  cfg = RasterConfig(use_alpha_blending=False, compute_visibility=True)
+  with pytest.raises(ValueError, match='compute_visibility'):
+    rasterize_with_tiles(p.to(DEV), f.to(DEV), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+
+
 def test_quantile_render_no_blending():
   # use_alpha_blending=False + saturate_threshold = median_threshold (renderer.py:77-82)
   size = (128, 96)

@@ -48,3 +48,15 @@ for seed in range(6):
       print(line)
     else:
       print(f"  {name}: max err/scale {e.max() / scale:.2e}")
+  # the worst rotation-gradient row of this seed in detail
+  got, want = a_h[2].grad.cpu().double(), a_o[2].grad
+  e = (got - want).abs().max(dim=1).values
+  wi = int(e.argmax())
+  vis_pos = (out_o[2] == wi).nonzero()
+  if vis_pos.numel():
+    k = int(vis_pos[0])
+    w_, h_ = camera.image_size
+    print(f"  worst rotation row {wi}: err {e[wi]:.3e}, |grad| {want[wi].abs().max():.3e}, depth {out_o[1][k].item():.4f} (near {camera.near_plane}), "
+          f"mean {out_o[0][k, :2].tolist()} image {w_}x{h_}, sigma {out_o[0][k, 4:6].tolist()}, alpha {out_o[0][k, 6].item():.3f}, "
+          f"log_scaling {a_o[1][wi].tolist()}, f32-vs-f64 point row err {(out_h[0][k].cpu().double() - out_o[0][k]).abs().tolist()}")
+    print(f"    grad f64 {want[wi].tolist()}\n    grad f32 {got[wi].tolist()}")
