@@ -6,8 +6,14 @@ Each configuration is checked twice:
     sizes gaussians as width / sqrt(n) pixels, so n / pixels fixed keeps the per-tile population), float32, on
     a GATE-STABLE scene: gaussians with a (pixel, splat) pair closer than 1e-4 (relative) to the blend gate
     alpha > alpha_threshold are removed first (oracle.raster.gate_margin), so no float32 rounding can flip a
-    gate and pixels AND gradients must agree to the 1e-4 of BASELINE.json's north_star everywhere, with no
-    quantile or absolute slack;
+    gate.  Pixels and the gradients at the 2D boundary (d gaussians2d, d colour) must then agree with the
+    float64 oracle to the 1e-4 of BASELINE.json's north_star EVERYWHERE, with no quantile or absolute slack.
+    The gradients of the 3D parameters go through the projection backward, whose float32 evaluation is
+    ill-conditioned for some gaussians in ANY implementation of the reference's formulas (eigen-decomposition of
+    a near-isotropic blurred covariance, quaternion normalisation): torch_lib's own arithmetic run in float32 is
+    off by up to ~10 % of the largest gradient on such rows.  They are therefore held to (a) 1e-4 against the
+    oracle evaluated in float32 on the same inputs, and (b) "no less accurate than the reference arithmetic":
+    error vs float64 <= 1e-4 of the largest gradient + 4 x the float32 oracle's own error, element by element;
   * at full size through size-independent properties: mapper invariants, the float32 product kernels against
     the float64 generic kernels on the same tile lists, tile-row strips composing to the full frame in image and
     in gradient, finite gradients."""
@@ -61,6 +67,19 @@ def oracle_frame(g, cam, cfg, G):
   return out
 
 
+def oracle_leaf_grads_f32(g, cam, cfg, grad_points, grad_feats):
+  """The projection / SH backward of the oracle evaluated in float32 (torch CPU), fed with the float64 oracle's
+  2D-boundary gradients: what torch_lib's own arithmetic yields at the precision the product runs in."""
+  g, cam = g.to(dtype=torch.float32), cam.to(dtype=torch.float32)
+  leaves = [getattr(g, k).detach().clone().requires_grad_(True) for k in LEAVES]
+  pos, ls, rot, al, feat = leaves
+  points, depths, idx = oproj.apply(pos, ls, rot, al, cam.T_camera_world, cam.projection, cam.image_size,
+                                    cam.depth_range, cfg.blur_cov, cfg.clamp_margin, cfg.alpha_threshold)
+  feats = osh.evaluate_sh_at(feat, pos.detach(), idx, torch.inverse(cam.T_camera_world)[0:3, 3])
+  torch.autograd.backward([points, feats], [grad_points.float(), grad_feats.float()])
+  return idx, [x.grad.double() for x in leaves]
+
+
 def gate_stable(g, cam, cfg, rel_margin=1e-4):
   """Drop the gaussians whose projected splat has a pixel within ``rel_margin`` of the blend gate."""
   o = oracle_frame(g, cam, cfg, None)
@@ -91,11 +110,22 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   err = (r.image.cpu().double() - want['image']).abs()
   assert err.max() < 1e-4, (name, err.max())                                # every pixel, no borderline mask
   assert (r.image_weight.cpu().double() - want['alpha']).abs().max() < 1e-4
+  r.points.gaussians2d.retain_grad()
+  r.points.features.retain_grad()
   (r.image * G.to(DEV).float()).sum().backward()
-  for k, w in zip(LEAVES, want['grads']):
-    got = getattr(gd, k).grad.cpu().double()
+  # 2D boundary: strict
+  for k, got, w in (('gaussians2d', r.points.gaussians2d.grad, want['grad_points']), ('features', r.points.features.grad, want['grad_feats'])):
     scale = w.abs().max().item()
-    assert (got - w).abs().max() < 1e-4 * scale, (name, k, (got - w).abs().max().item(), scale)
+    assert (got.cpu().double() - w).abs().max() < 1e-4 * scale, (name, k, (got.cpu().double() - w).abs().max().item(), scale)
+  # 3D parameters: see the module docstring
+  idx32, ref32 = oracle_leaf_grads_f32(g, cam, cfg, want['grad_points'], want['grad_feats'])
+  assert torch.equal(idx32, want['idx'])
+  for k, w64, w32 in zip(LEAVES, want['grads'], ref32):
+    got = getattr(gd, k).grad.cpu().double()
+    scale = w64.abs().max().item()
+    assert (got - w32).abs().max() < 1e-4 * scale, (name, k, 'vs float32 oracle', (got - w32).abs().max().item(), scale)
+    excess = (got - w64).abs() - 4 * (w32 - w64).abs()
+    assert excess.max() < 1e-4 * scale, (name, k, 'vs float64 oracle', excess.max().item(), scale)
 
 
 @pytest.mark.parametrize('tile', [8, 16, 32])

@@ -1,8 +1,12 @@
 """-m gpu: the raster forward/backward kernels (through the C-ABI) vs the oracle.
 
 Tolerances: float64 1e-9 (same algorithm, different summation order); float32 1e-4 absolute on
-pixels and 1e-4 relative-to-scale on gradients (BASELINE.json north_star: "pixels/grads within
-1e-4"), excluding pixels where some splat sits numerically on the alpha_threshold gate."""
+pixels and 1e-4 of the largest gradient on gradients (BASELINE.json north_star: "pixels/grads within
+1e-4"), for EVERY pixel and EVERY splat, on GATE-STABLE scenes: the blend gate ``alpha > alpha_threshold``
+(forward.py:99-101) is a discontinuity, a (pixel, splat) pair within float32 rounding of it may legitimately fall
+on either side, and one flipped gate moves that pixel by ~alpha_threshold * |f| and the gradients of every splat
+behind it.  ``gate_stable`` removes the splats that have such a pair (closer than 1e-4 relative, measured by the
+float64 oracle: oracle.raster.gate_margin) before the comparison, so nothing is masked or averaged afterwards."""
 from dataclasses import replace
 
 import numpy as np
@@ -28,6 +32,22 @@ def scene(n, size, seed, scale=1.0, alpha=(0.1, 0.9), channels=3, tile_size=16, 
 
 def cfg_for(tile_size, **kw):
   return RasterConfig(tile_size=tile_size, pixel_stride=(1, 1) if tile_size == 8 else (2, 2), **kw)
+
+
+def gate_stable(g, size, cfg, rel_margin=1e-4):
+  """The 2D gaussians of ``g`` that have no (pixel, splat) pair within ``rel_margin`` of the blend gate."""
+  p = project_gaussians2d(g)
+  o2p, ranges = map_to_tiles(p.to(DEV), g.depths.to(DEV), size, cfg)
+  margin = orast.gate_margin(p.double().cpu(), ranges.cpu(), o2p.cpu(), size, cfg)
+  keep = margin > rel_margin
+  assert keep.float().mean() > 0.7
+  return g[keep.to(g.position.device)]
+
+
+def assert_within(got, want, tol, what):
+  scale = want.abs().max().item()
+  err = (got.cpu().double() - want.cpu().double()).abs().max().item()
+  assert err < tol * max(scale, 1e-30), (what, err, scale)
 
 
 @pytest.mark.parametrize('tile_size', [8, 16, 32])
@@ -61,27 +81,23 @@ def test_forward_backward_f32_config_a(tile_size):
   # BASELINE config A shape: 10k random 2D gaussians, 256x256
   size = (256, 256)
   cfg = cfg_for(tile_size)
-  p, f, d, o2p, ranges = scene(10000, size, seed=0, tile_size=tile_size)
+  torch.manual_seed(0)
+  g = gate_stable(random_2d_gaussians(10000, size), size, cfg)
+  p, f = project_gaussians2d(g), g.feature
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, tile_size)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
   img_o, a_o, _, border = orast.forward(p.double(), f.double(), ranges, o2p, size, cfg, return_borderline=True)
+  assert not bool(border.any())
   pg, fg = p.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
   out = rasterize_with_tiles(pg, fg, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
-  ok = ~border
-  assert ok.float().mean() > 0.999
-  err = (out.image.cpu().double() - img_o).abs().max(-1).values
-  assert err[ok].max() < 1e-4, err[ok].max()
-  assert (out.image_weight.cpu().double() - a_o).abs()[ok].max() < 1e-4
-  assert err.max() < 2e-2        # a flipped gate changes a pixel by at most ~alpha_threshold * |f|
+  assert (out.image.cpu().double() - img_o).abs().max() < 1e-4              # every pixel
+  assert (out.image_weight.cpu().double() - a_o).abs().max() < 1e-4
 
   G = torch.ones_like(img_o)
   gp_o, gf_o, _ = orast.backward(p.double(), f.double(), ranges, o2p, img_o, G, size, cfg)
   out.image.sum().backward()
-  for got, want in ((pg.grad, gp_o), (fg.grad, gf_o)):
-    scale = want.abs().max().item()
-    assert (got.cpu().double() - want).abs().max() < 1e-4 * max(1.0, scale) + 5e-3, \
-      ((got.cpu().double() - want).abs().max(), scale)
-    # and tightly in the bulk
-    rel = (got.cpu().double() - want).abs() / (want.abs() + 1e-2 * scale)
-    assert rel.quantile(0.999) < 1e-3
+  assert_within(pg.grad, gp_o, 1e-4, 'd gaussians2d')                        # every splat, 1e-4 of the largest gradient
+  assert_within(fg.grad, gf_o, 1e-4, 'd features')
 
 
 @pytest.mark.parametrize('antialias', [False, True])
@@ -231,12 +247,12 @@ def test_empty_inputs_and_requires_grad_subsets():
 @pytest.mark.parametrize('n,size,scale,alpha', [(20000, (333, 200), 1.0, (0.1, 0.9)), (8000, (96, 64), 6.0, (0.6, 1.0)),
                                                  (200000, (1024, 768), 1.0, (0.1, 0.9))])
 def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale, alpha):
-  # the hand-tuned float/RGB kernels (raster_fast.hip) against the generic f64 instantiation
-  # (itself checked against the oracle above), incl. many LDS batches per tile, image sizes that are
-  # not tile multiples, point heuristics
+  # the hand-tuned float/RGB kernels (raster_fast.hip forward, raster_bwd_scan.hip backward) against the generic
+  # f64 instantiation (itself checked against the oracle above), incl. many LDS batches per tile, image sizes
+  # that are not tile multiples, point heuristics, visibility — on a gate-stable scene, strictly
   torch.manual_seed(n + tile_size)
   cfg = cfg_for(tile_size, compute_point_heuristic=True, compute_visibility=True)
-  g = random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha).to(DEV)
+  g = gate_stable(random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha), size, cfg).to(DEV)
   p32 = project_gaussians2d(g)
   o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
   ranges = ranges.view(-1, 2)
@@ -252,26 +268,20 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
                   out.point_heuristic.double(), out.visibility.double())
   img64, a64, gp64, gf64, h64, v64 = res[torch.float64]
   img32, a32, gp32, gf32, h32, v32 = res[torch.float32]
-  err = (img32 - img64).abs().max(-1).values
-  # a contribution gate (alpha > 1/255) flipping in f32 moves a pixel by ~alpha_threshold * |f|
-  assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2, (err.quantile(0.9999), err.max())
-  assert (a32 - a64).abs().quantile(0.9999) < 1e-4
+  assert (img32 - img64).abs().max() < 1e-4 and (a32 - a64).abs().max() < 1e-4
   assert v64.sum() > 0
-  for got, want in ((gp32, gp64), (gf32, gf64), (h32, h64), (v32, v64)):
-    scale_ = want.abs().max().item() + 1e-12
-    rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
-    assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
-    assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
+  for what, got, want in (('d gaussians2d', gp32, gp64), ('d features', gf32, gf64), ('heuristics', h32, h64), ('visibility', v32, v64)):
+    assert_within(got, want, 1e-4, what)
 
 
 @pytest.mark.parametrize('tile_size,n,size,scale,alpha', [(16, 20000, (333, 200), 1.0, (0.1, 0.9)), (8, 6000, (96, 64), 5.0, (0.5, 1.0)),
                                                           (32, 100000, (640, 480), 1.5, (0.02, 0.9))])
 def test_f32_antialias_matches_f64(tile_size, n, size, scale, alpha):
   # antialiased pdf: the float kernels use v_exp_f32 / v_rcp_f32 and the contribution-rectangle cull; the f64
-  # instantiation (exact formulation, checked against the oracle above) is the reference
+  # instantiation (exact formulation, checked against the oracle above) is the reference; gate-stable scene
   torch.manual_seed(n)
   cfg = cfg_for(tile_size, antialias=True, compute_point_heuristic=True, compute_visibility=True)
-  g = random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha).to(DEV)
+  g = gate_stable(random_2d_gaussians(n, size, scale_factor=scale, alpha_range=alpha), size, cfg).to(DEV)
   p32 = project_gaussians2d(g)
   o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
   ranges = ranges.view(-1, 2)
@@ -285,12 +295,7 @@ def test_f32_antialias_matches_f64(tile_size, n, size, scale, alpha):
     (out.image * G.to(dtype)).sum().backward()
     res[dtype] = (out.image.detach().double(), p.grad.double(), f.grad.double(), out.point_heuristic.double(),
                   out.visibility.double())
-  img64, img32 = res[torch.float64][0], res[torch.float32][0]
-  err = (img32 - img64).abs().max(-1).values
-  assert err.quantile(0.9999) < 1e-4 and err.max() < 2e-2, (err.quantile(0.9999), err.max())
+  assert (res[torch.float32][0] - res[torch.float64][0]).abs().max() < 1e-4
   assert res[torch.float64][1].abs().sum() > 0
-  for got, want in zip(res[torch.float32][1:], res[torch.float64][1:]):
-    scale_ = want.abs().max().item() + 1e-12
-    rel = (got - want).abs() / (want.abs() + 1e-3 * scale_)
-    assert rel.quantile(0.999) < 2e-3, rel.quantile(0.999)
-    assert (got - want).abs().max() < 2e-2 * scale_, ((got - want).abs().max(), scale_)
+  for what, got, want in zip(('d gaussians2d', 'd features', 'heuristics', 'visibility'), res[torch.float32][1:], res[torch.float64][1:]):
+    assert_within(got, want, 1e-4, what)
