@@ -37,15 +37,17 @@ def install_as_taichi_splatting():
   me = sys.modules[__name__]
   sys.modules.setdefault('taichi_splatting', me)
   for sub in ('data_types', 'renderer', 'rendering', 'taichi_queue', 'spherical_harmonics',
-              'indexed_spherical_harmonics', 'perspective', 'perspective.params',
+              'perspective', 'perspective.params',
               'perspective.projection', 'mapper', 'mapper.tile_mapper', 'rasterizer',
               'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'misc.morton_sort', 'optim', 'optim.fractional',
-              'optim.visibility_aware', 'optim.parameter_class', 'optim.autograd', 'optim.util',
-              'benchmarks', 'benchmarks.util', 'benchmarks.bench_projection', 'benchmarks.bench_sh',
-              'benchmarks.bench_tilemapper', 'benchmarks.bench_rasterizer', 'examples',
+              'optim.visibility_aware', 'optim.parameter_class', 'benchmarks', 'examples',
               'examples.fit_image_gaussians'):
     mod = importlib.import_module(f'{__name__}.{sub}')
     sys.modules.setdefault(f'taichi_splatting.{sub}', mod)
+  # module names of the reference whose contents live elsewhere here: evaluate_sh_at (reference
+  # indexed_spherical_harmonics.py:166) is in spherical_harmonics, restore_grad (optim/autograd.py) in optim.fractional
+  for alias, target in (('indexed_spherical_harmonics', 'spherical_harmonics'), ('optim.autograd', 'optim.fractional')):
+    sys.modules.setdefault(f'taichi_splatting.{alias}', importlib.import_module(f'{__name__}.{target}'))
   # the reference keeps its scene generators under tests/ (tests/random_data.py)
   testing = importlib.import_module(f'{__name__}.testing')
   sys.modules.setdefault('taichi_splatting.tests', testing)

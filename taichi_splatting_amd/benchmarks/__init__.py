@@ -1,3 +1,4 @@
-"""Component benchmarks with the command lines of the reference's ``benchmarks/`` package
-(bench_projection, bench_sh, bench_tilemapper, bench_rasterizer): same workloads and flags, timed with
-HIP events on the launch stream.  ``python -m taichi_splatting_amd.benchmarks.bench_rasterizer``."""
+"""Component benchmarks: ``python -m taichi_splatting_amd.benchmarks [stage ...] [--iters N]`` times the stages of
+the render path on the workloads the reference's ``benchmarks/`` package and SURVEY.md 8(d) name
+(see ``components.WORKLOADS``), with HIP events on the launch stream."""
+from .components import WORKLOADS, run, time_ms   # noqa: F401

@@ -79,6 +79,14 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// v_min_f32 with the wave-uniform operand read straight from its SGPR (min_f32() of raster_common.h takes two
+// VGPRs and costs a v_mov_b32 per use when one side is a kernel argument)
+__device__ __forceinline__ float min_f32_uniform(float a, float uniform_b) {
+  float r;
+  asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform_b));
+  return r;
+}
+
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 // 48-byte LDS record of a staged splat:
@@ -298,27 +306,36 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
               const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
               const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X, X, __builtin_fmaf(Y, Y, nl2a)));
-              const bool contrib = a_raw > rp.alpha_threshold;
-              const float a_clamped = min_f32(a_raw, rp.clamp_max_alpha);
-              const float a = contrib ? a_clamped : 0.0f;
+              // blend gate (forward.py:99-101): lanes below the threshold carry alpha = 0 from here on
+              const float a_gated = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
+              float a = min_f32_uniform(a_gated, rp.clamp_max_alpha);
               const float om = 1.0f - a;
               // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
               const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
-              const float w = Tk > oms ? a * Tk : 0.0f;                             // saturation skip (backward.py:154)
+              // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
+              // The pixel can cross that line inside at most one chunk of its life: wave-uniform slow path.
+              float a_st = a_gated;                                                // straight-through alpha (below)
+              if (__ballot(!(Tk > oms)) != 0) {
+                asm volatile("; saturation inside the chunk" ::: "memory");        // keep this a branch, not two selects per value
+                const bool live = Tk > oms;
+                a = live ? a : 0.0f;
+                a_st = live ? a_gated : 0.0f;
+              }
+              const float w = a * Tk;
               const float g0 = cur.x, g1 = cur.y, g2 = cur.z;
               const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
               // <R, G> after this splat: R -= f w  (backward.py:171-174)
               const float RGk = RGin - wave_scan_add(w * fG);
               // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
               const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
-              // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha)
-              const float q_ = w != 0.0f ? ag * a_raw : 0.0f;
+              // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
+              const float q_ = ag * a_st;
               const float qX = q_ * X, qY = q_ * Y;
               m0 += q_; m1 += qX; m2 += qY;
               m3 = __builtin_fmaf(qX, X, m3); m4 = __builtin_fmaf(qX, Y, m4); m5 = __builtin_fmaf(qY, Y, m5);
               a0 = __builtin_fmaf(w, g0, a0); a1 = __builtin_fmaf(w, g1, a1); a2 = __builtin_fmaf(w, g2, a2);
               if (HEUR) {                                           // backward.py:190-194
-                const float agm = w != 0.0f ? ag : 0.0f;
+                const float agm = a_st != 0.0f ? ag : 0.0f;
                 h0 = __builtin_fmaf(agm, agm, h0);
                 h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
               }

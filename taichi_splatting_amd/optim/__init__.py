@@ -1,8 +1,7 @@
 """Visibility-aware sparse optimisers (reference ``optim/__init__.py``): the step that consumes the
 render path's outputs (gradients + visibility of the points in view) each iteration."""
-from .autograd import restore_grad
 from .parameter_class import ParameterClass
-from .fractional import FractionalAdam, FractionalLaProp, SparseAdam, SparseLaProp
+from .fractional import FractionalAdam, FractionalLaProp, SparseAdam, SparseLaProp, restore_grad
 from .visibility_aware import VisibilityAwareAdam, VisibilityAwareLaProp, VisibilityOptimizer
 
 __all__ = ['ParameterClass',

@@ -12,7 +12,55 @@ from typing import Optional, Tuple
 import torch
 
 from .. import _lib
-from .util import get_scalar_state, get_total_weight, get_vector_state
+
+
+class PointState:
+  """Lazily created per-point optimiser state inside a torch ``Optimizer.state`` entry.
+
+  Keys and shapes are the reference's (``optim/util.py``), including its naming quirk, so state dicts stay
+  interchangeable: ``'v'`` is the (N, D) FIRST moment, ``'m'`` the second moment — (N, D) for scalar groups,
+  (N,) for vector groups (one second moment per point from the squared gradient norm); ``'total_weight'`` and
+  ``'running_vis'`` are (N,) float32 and live in the FIRST parameter group's state."""
+
+  def __init__(self, state: dict):
+    self.state = state
+
+  def _get(self, key: str, make):
+    if key not in self.state:
+      self.state[key] = make()
+    return self.state[key]
+
+  def moments(self, param: torch.Tensor, per_point_second_moment: bool):
+    rows = param.view(param.shape[0], -1)
+    first = self._get('v', lambda: torch.zeros_like(rows))
+    second = self._get('m', (lambda: rows.new_zeros((rows.shape[0],))) if per_point_second_moment
+                       else (lambda: torch.zeros_like(rows)))
+    return first, second
+
+  def per_point(self, key: str, n: int, device) -> torch.Tensor:
+    return self._get(key, lambda: torch.zeros((n,), dtype=torch.float32, device=device))
+
+
+class restore_grad:
+  """``with restore_grad(a, b): ...`` — inside the block the tensors that require grad start from a zero
+  ``.grad``; on exit every tensor gets back the ``.grad`` it had before (reference ``optim/autograd.py``: used to
+  take a side gradient, e.g. of a regulariser, without disturbing the accumulated one)."""
+
+  def __init__(self, *tensors: torch.Tensor):
+    self.tensors = tensors
+    self.saved = None
+
+  def __enter__(self):
+    self.saved = [t.grad for t in self.tensors]
+    for t in self.tensors:
+      if t.requires_grad:
+        t.grad = torch.zeros_like(t)
+    return self
+
+  def __exit__(self, *exc):
+    for t, g in zip(self.tensors, self.saved):
+      t.grad = g
+    return False
 
 ADAM, LAPROP = 0, 1
 
@@ -69,14 +117,10 @@ def fractional_step(kind: int, vector: bool, lr_step, indexes, weight, m, v, tot
 def weighted_step(group: Group, visible_weight: torch.Tensor, visible_indexes: torch.Tensor,
                   total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None):
   """reference optim/fractional.py:108-156"""
-  if group.type in ["vector", "local_vector"]:
-    m, v = get_vector_state(group.state, group.param)
-    vector = True
-  elif group.type == "scalar":
-    m, v = get_scalar_state(group.state, group.param)
-    vector = False
-  else:
+  if group.type not in GROUP_TYPES:
     raise ValueError(f"unknown group type {group.type}")
+  vector = group.type != "scalar"
+  m, v = PointState(group.state).moments(group.param, per_point_second_moment=vector)
 
   grad = group.grad
   if group.type == "local_vector":
@@ -112,10 +156,7 @@ def fused_update(group: Group, visible_weight: torch.Tensor, visible_indexes: to
   (reference optim/fractional.py:108-156,190-195) — as ONE kernel, ``ms_fractional_update``."""
   if group.type not in GROUP_TYPES:
     raise ValueError(f"unknown group type {group.type}")
-  if group.type == "scalar":
-    m, v = get_scalar_state(group.state, group.param)
-  else:
-    m, v = get_vector_state(group.state, group.param)
+  m, v = PointState(group.state).moments(group.param, per_point_second_moment=group.type != "scalar")
   if group.type == "local_vector":
     assert basis is not None, "basis is required for local_vector optimizer"
     d = group.param.shape[1]
@@ -168,7 +209,7 @@ class FractionalOpt(torch.optim.Optimizer):
     groups = [make_group(group, self.state) for group in self.param_groups]
     n = groups[0].param.shape[0]
 
-    total_weight = get_total_weight(groups[0].state, n, device=weight.device)
+    total_weight = PointState(groups[0].state).per_point('total_weight', n, weight.device)
     total_weight[indexes] += weight
 
     for group in groups:

@@ -8,8 +8,7 @@ from typing import Optional
 
 import torch
 
-from .fractional import ADAM, LAPROP, fused_update, make_group, saturate, weighted_step  # noqa: F401
-from .util import get_running_vis, get_total_weight
+from .fractional import ADAM, LAPROP, PointState, fused_update, make_group, saturate, weighted_step  # noqa: F401
 
 
 def lerp(t, a, b):
@@ -54,8 +53,9 @@ class VisibilityOptimizer(torch.optim.Optimizer):
     groups = [make_group(group, self.state) for group in self.param_groups]
     n = groups[0].num_points
 
-    total_weight = get_total_weight(groups[0].state, n, device=visibility.device)
-    running_vis = get_running_vis(groups[0].state, n, device=visibility.device)
+    shared = PointState(groups[0].state)
+    total_weight = shared.per_point('total_weight', n, visibility.device)
+    running_vis = shared.per_point('running_vis', n, visibility.device)
 
     weight = update_visibility(running_vis, visibility, indexes, total_weight, self.vis_beta)
     total_weight[indexes] += weight
