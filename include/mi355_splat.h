@@ -199,13 +199,17 @@ int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile
  *           (backward.py:190-194)
  * Every geometric gradient of gaussian_pdf_with_grad (generic.py:321-336) is a per-splat linear map of these
  * sums; ms_raster_moments_finalize applies it once per point and STORES grad_points7 (V,7), grad_features
- * (V,3) and point_heuristic (V,2) (each may be NULL). */
+ * (V,3) and point_heuristic (V,2) (each may be NULL).
+ *
+ * deterministic != 0: `moments` is (V, MS_MOMENT_ROW) INT64 (128 bytes per point, pre-zeroed) and the per-patch
+ * sums are committed in 2^-32 fixed point with integer atomics, which makes the gradients bitwise reproducible
+ * from run to run (float atomics add in arrival order).  Pass the same flag to both functions. */
 #define MS_MOMENT_ROW 16
 int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
                           const int32_t* overlap_to_point, const void* image, const void* grad_image,
                           int image_w, int image_h, const ms_raster_config* cfg, float* moments,
-                          int tile_row_begin, int tile_row_end, void* stream);
-int ms_raster_moments_finalize(const void* points7, const float* moments, int64_t n,
+                          int deterministic, int tile_row_begin, int tile_row_end, void* stream);
+int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic, int64_t n,
                                float* grad_points7, float* grad_features, float* point_heuristic,
                                void* stream);
 

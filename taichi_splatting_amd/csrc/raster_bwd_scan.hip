@@ -50,6 +50,11 @@ __device__ unsigned long long g_scan_stats[8];
 #endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
+// Deterministic mode: the per-(patch, splat) sums are committed as 64-bit fixed-point integers (2^-32 units,
+// |sum| < 2^31) with INTEGER atomics.  Integer addition is associative, so the accumulated row does not depend on
+// the order in which the patches of different tiles reach memory and the gradients are bitwise reproducible;
+// everything before the commit (scans, per-lane sums, per-wave LDS rows) already runs in program order.
+constexpr float FIXED_POINT_SCALE = 4294967296.0f;
 
 // Inclusive prefix product / sum over the 64 lanes: row_shr:1,2,4,8 build the 16-lane row prefixes, row_bcast:15
 // (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row totals — six DPP instructions.  Lanes without a source
@@ -373,7 +378,12 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         if (k < NACC) {
           const float v = s_acc[wave][e][k];
           if (v != 0.0f) {
-            atomic_add_noret(moments + (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k, v);
+            const size_t word = (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k;
+            if (rp.deterministic)
+              __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word, (long long)llrintf(v * FIXED_POINT_SCALE),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+              atomic_add_noret(moments + word, v);
             s_acc[wave][e][k] = 0.0f;
           }
         }
@@ -389,15 +399,24 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 //   d mean  = M^T (Sx, Sy)                                  d sigma = (Sxx / sx, Syy / sy)
 //   d axis  = sum q (X/sx (-d) + Y/sy perp(d)),  d = M^-1 (X, Y)     d alpha = S / alpha      (generic.py:321-336)
 // The kernel stores the moments of (X', Y') = s (X, Y), s = sqrt(log2(e) / 2).
-template <bool HEUR>
+template <bool HEUR, bool FIXED>
 __global__ void __launch_bounds__(256)
 raster_moments_finalize_kernel(const float* __restrict__ points, const float* __restrict__ moments, int64_t n,
                                float* __restrict__ grad_points, float* __restrict__ grad_feats,
                                float* __restrict__ heuristic) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4* row = reinterpret_cast<const float4*>(moments + i * MOMENT_ROW);
-  const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+  float4 r0, r1, r2;
+  if (FIXED) {       // deterministic mode: rows of 64-bit fixed-point integers
+    const long long* row = reinterpret_cast<const long long*>(moments) + i * MOMENT_ROW;
+    float v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = (float)((double)row[k] * (1.0 / (double)FIXED_POINT_SCALE));
+    r0 = make_float4(v[0], v[1], v[2], v[3]); r1 = make_float4(v[4], v[5], v[6], v[7]); r2 = make_float4(v[8], v[9], v[10], v[11]);
+  } else {
+    const float4* row = reinterpret_cast<const float4*>(moments + i * MOMENT_ROW);
+    r0 = row[0]; r1 = row[1]; r2 = row[2];
+  }
   if (grad_points) {
     const float* g = points + i * 7;
     const float ax = g[2], ay = g[3], sx = g[4], sy = g[5], alpha = g[6];
@@ -434,7 +453,7 @@ using namespace ms;
 extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
                                      const int32_t* overlap_to_point, const void* image, const void* grad_image,
                                      int image_w, int image_h, const ms_raster_config* cfg, float* moments,
-                                     int tile_row_begin, int tile_row_end, void* stream) {
+                                     int deterministic, int tile_row_begin, int tile_row_end, void* stream) {
   MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments, "null pointer");
   MS_CHECK_ARG(image_w > 0 && image_h > 0, "bad image size");
   MS_CHECK_ARG(cfg->use_alpha_blending, "backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)");
@@ -451,6 +470,7 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
   rp.clamp_max_alpha = (float)cfg->clamp_max_alpha;
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
+  rp.deterministic = deterministic != 0;
   const dim3 grid((unsigned)((tile_row_end - tile_row_begin) * tiles_wide));
   hipStream_t s = (hipStream_t)stream;
 #define MS_GO(TS, HEUR) raster_bwd_scan_kernel<TS, HEUR><<<grid, dim3(TS * TS), 0, s>>>(                       \
@@ -475,7 +495,7 @@ extern "C" int ms_debug_scan_stats(unsigned long long* out8, int reset) {
 }
 #endif
 
-extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int64_t n,
+extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic, int64_t n,
                                           float* grad_points7, float* grad_features, float* point_heuristic,
                                           void* stream) {
   MS_CHECK_ARG(n >= 0, "negative size");
@@ -484,8 +504,11 @@ extern "C" int ms_raster_moments_finalize(const void* points7, const float* mome
   if (!grad_points7 && !grad_features && !point_heuristic) return 0;
   const dim3 grid((unsigned)div_up(n, 256));
   hipStream_t s = (hipStream_t)stream;
-  if (point_heuristic) raster_moments_finalize_kernel<true><<<grid, 256, 0, s>>>((const float*)points7, moments, n, grad_points7, grad_features, point_heuristic);
-  else raster_moments_finalize_kernel<false><<<grid, 256, 0, s>>>((const float*)points7, moments, n, grad_points7, grad_features, nullptr);
+#define MS_GO(HEUR, FIXED) raster_moments_finalize_kernel<HEUR, FIXED><<<grid, 256, 0, s>>>(            \
+      (const float*)points7, moments, n, grad_points7, grad_features, point_heuristic)
+  if (point_heuristic) { if (deterministic) MS_GO(true, true); else MS_GO(true, false); }
+  else { if (deterministic) MS_GO(false, true); else MS_GO(false, false); }
+#undef MS_GO
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -9,6 +9,7 @@ namespace ms {
 struct FastParams {
   int width, height, tiles_wide, tile_begin;
   float clamp_max_alpha, alpha_threshold, one_minus_saturate;
+  int deterministic;      // raster_bwd_scan.hip: order-independent (fixed-point integer) gradient commits
 };
 
 // raw per-splat data in flight between the gather and the LDS write (one batch ahead)

@@ -301,6 +301,7 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
   rp.clamp_max_alpha = (float)cfg->clamp_max_alpha;
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
+  rp.deterministic = 0;
   return rp;
 }
 

@@ -26,6 +26,12 @@ MAX_KERNEL_FEATURES = 4   # csrc/raster.hip instantiates F = 1..4; wider feature
 WIDE_KERNEL_FEATURES = (8, 16)   # backward with point heuristics: instantiated too (zero-padded up to these widths)
 
 
+# Bitwise reproducible gradients for the product path (float32 RGB): fixed-point integer commits instead of float
+# atomics (csrc/raster_bwd_scan.hip).  Set the module attribute or MS_DETERMINISTIC=1; costs a 128 B instead of
+# 64 B accumulator row per gaussian.  RasterConfig stays the reference's dataclass, hence no field there.
+DETERMINISTIC_BACKWARD = os.environ.get('MS_DETERMINISTIC', '0') not in ('0', '')
+
+
 def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
   """Product path (float32 RGB, plain pdf): csrc/raster_bwd_scan.hip.  ``MS_RASTER_BWD=patch`` selects the
   pixel-per-lane kernels of raster_fast.hip instead (A/B measurements only)."""
@@ -167,12 +173,13 @@ class _RasterFunction(torch.autograd.Function):
     cfg_c = _lib.raster_config_c(config)
 
     if moments_path:
-      moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.float32, device=gaussians.device)
+      det = int(DETERMINISTIC_BACKWARD)
+      moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.int64 if det else torch.float32, device=gaussians.device)
       _lib.check(lib.ms_raster_bwd_moments(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                            _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
-                                           grad_image.data_ptr() - row_bytes * f, w, h, cfg_c, moments.data_ptr(),
+                                           grad_image.data_ptr() - row_bytes * f, w, h, cfg_c, moments.data_ptr(), det,
                                            ctx.rows[0], ctx.rows[1], stream), "rasterize backward")
-      _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), n, _lib.ptr(grad_gaussians),
+      _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), det, n, _lib.ptr(grad_gaussians),
                                                 _lib.ptr(grad_features), _lib.ptr(heuristic), stream),
                  "rasterize backward (moments -> gradients)")
     elif f > MAX_KERNEL_FEATURES and heuristic is not None:
