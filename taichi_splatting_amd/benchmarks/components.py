@@ -64,8 +64,9 @@ def _with_grad(tensors, wanted, body):
 
 
 def projection_cases(device, n=2_000_000, margin=0.5) -> Cases:
-  camera = random_camera().to(device)
+  camera = random_camera()
   g = random_3d_gaussians(n, camera, margin=margin).to(device)       # ~half of them outside the view
+  camera = camera.to(device=device)
   cfg = RasterConfig()
   shape = list(g.shape_tensors())
   cam = [camera.T_camera_world, camera.projection]
@@ -86,7 +87,7 @@ def _no_grad(fn):
 
 
 def sh_cases(device, n=1_000_000, degree=3) -> Cases:
-  camera_pos = random_camera().to(device).camera_position.clone()
+  camera_pos = random_camera().to(device=device).camera_position.clone()
   params = torch.rand(n, 3, (degree + 1) ** 2, device=device)
   points = torch.randn(n, 3, device=device)
   indexes = torch.arange(n, device=device)
@@ -134,7 +135,7 @@ def rasterizer_cases(device, n=1_000_000, size=(1024, 768), scale=4.0, tile=16) 
 def rasterizer_config_d_cases(device, n=6_000_000, size=(2048, 2048), tile=16) -> Cases:
   camera = random_camera(image_size=size)
   g = random_3d_gaussians(n, camera, scale_factor=1.0, alpha_range=(0.1, 0.9), margin=0.0).to(device)
-  camera = camera.to(device)
+  camera = camera.to(device=device)
   cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
   with torch.no_grad():
     p, depth, idx = project_to_image(g, camera, cfg)

@@ -6,8 +6,7 @@ Same interface as reference ``renderer.py:23-108`` (``render_gaussians``, ``rend
 from __future__ import annotations
 
 from dataclasses import replace
-import os
-from typing import Callable, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -18,16 +17,6 @@ from .perspective.projection import project_to_image
 from .rasterizer.function import rasterize_with_tiles
 from .rendering import RenderedPoints, Rendering, ndc_depth
 from .spherical_harmonics import evaluate_sh_at
-
-
-_side_streams = {}
-
-
-def _side_stream(device: torch.device) -> "torch.cuda.Stream":
-  key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-  if key not in _side_streams:
-    _side_streams[key] = torch.cuda.Stream(device=device)
-  return _side_streams[key]
 
 
 def render_gaussians(
@@ -54,51 +43,29 @@ def render_gaussians(
   """
   gaussians2d, depths, indexes = project_to_image(gaussians, camera_params, config)
 
-  join = None
   if use_sh:
-    camera_position = camera_params.camera_position
-    if gaussians2d.is_cuda and os.environ.get('MS_OVERLAP_SH', '1') != '0':
-      # The SH colours are needed by the rasterizer only: evaluate them on a second HIP stream while the tile
-      # mapper runs on the current one.  The mapper is ~30 short, launch-latency-bound kernels around one host
-      # synchronisation, the SH pass one long HBM-bound stream (192 B per gaussian at degree 3); they share the
-      # device without slowing each other.  Autograd replays the backward of each op on its forward stream and
-      # orders the streams itself.
-      main, side = torch.cuda.current_stream(gaussians2d.device), _side_stream(gaussians2d.device)
-      side.wait_stream(main)
-      with torch.cuda.stream(side):
-        features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_position,
-                                  unique_indexes=True)
-      features.record_stream(main)
-
-      def join():
-        main.wait_stream(side)
-    else:
-      features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_position,
-                                unique_indexes=True)
+    features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes,
+                              camera_params.camera_position, unique_indexes=True)
   else:
     features = gaussians.feature[indexes]
     assert len(features.shape) == 2, f"Features must be (N, C) if use_sh=False, got {features.shape}"
 
   return render_projected(indexes, gaussians2d, features, depths, camera_params, config,
                           use_depth16=use_depth16, render_median_depth=render_median_depth,
-                          tile_rows=tile_rows, before_rasterize=join)
+                          tile_rows=tile_rows)
 
 
 def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features: torch.Tensor,
                      depths: torch.Tensor, camera_params: CameraParams, config: RasterConfig,
                      use_depth16: bool = False, render_median_depth: bool = False,
-                     tile_rows: Optional[Tuple[int, int]] = None, crop_to_rows: bool = False,
-                     before_rasterize: Optional[Callable[[], None]] = None) -> Rendering:
+                     tile_rows: Optional[Tuple[int, int]] = None, crop_to_rows: bool = False) -> Rendering:
   # crop_to_rows: with tile_rows, the images hold only the strip's pixel rows (multi-GPU strips)
-  # before_rasterize: called between the tile mapper and the rasterizer (joins the stream `features` is computed on)
   # ndc depth (renderer.py:67) is computed inside the mapper's key kernel
   overlap_to_point, tile_overlap_ranges = map_to_tiles_strip(
     gaussians2d, depths.detach(), image_size=camera_params.image_size, config=config,
     use_depth16=use_depth16, tile_rows=tile_rows,
     ndc_range=(camera_params.near_plane, camera_params.far_plane))
 
-  if before_rasterize is not None:
-    before_rasterize()
   raster = rasterize_with_tiles(
     gaussians2d, features,
     tile_overlap_ranges=tile_overlap_ranges.view(-1, 2), overlap_to_point=overlap_to_point,
