@@ -210,7 +210,8 @@ def respawn_under_torchrun(args):
     print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
     sys.exit(2)
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-         '--master-addr', '127.0.0.1', '--master-port', str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+         '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
+         '--', str(Path(__file__).resolve())] + sys.argv[1:]   # '--': the launcher's argparse would prefix-match e.g. --n
   env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
   sys.exit(subprocess.call(cmd, env=env))
 

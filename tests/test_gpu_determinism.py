@@ -41,7 +41,8 @@ def test_deterministic_backward_is_bitwise_repeatable(n, size, tile, monkeypatch
   for other in runs[1:]:
     for a, b in zip(runs[0], other):
       assert torch.equal(a, b)                                  # image, 2D-boundary and 3D gradients: bit for bit
-  # and it is the same gradient: the fixed-point commit rounds each per-patch sum to 2^-32
+  # and it is the same gradient: the fixed-point commit rounds each per-patch sum to 2^-32; the float-atomic
+  # result itself moves by ~1e-5 of the largest gradient from run to run
   for a, b in zip(runs[0], plain):
     scale = b.abs().max().item()
-    assert (a - b).abs().max().item() <= 1e-5 * scale
+    assert (a - b).abs().max().item() <= 1e-4 * scale
