@@ -52,6 +52,7 @@ def parse_args():
                       'all-to-all of projected splats; strips = replicated gaussians + all-reduce (north_star); '
                       'auto = both for N > 1 (value = the faster one)')
   p.add_argument('--forward-only', action='store_true')
+  p.add_argument('--even-strips', action='store_true', help='N > 1: equal tile rows per rank instead of overlap-balanced strips')
   p.add_argument('--launcher', action='store_true',
                  help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
   return p.parse_args()
@@ -225,6 +226,17 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
 
   g = scene
   shard_begin = 0
+  bounds = None
+  if world > 1 and not args.even_strips:
+    # strips cut where the per-tile-row overlap histogram says, once for this (static) scene and camera, outside
+    # the timed region: the gaussians' projection is replicated work here, one small all-reduce for sharded input
+    from taichi_splatting_amd.distributed import overlap_balanced_bounds
+    from taichi_splatting_amd.perspective.projection import project_to_image
+    with torch.no_grad():
+      part = scene if mode == 'strips' else scene[slice(*shard_range(args.n, world, rank))]
+      bounds = overlap_balanced_bounds(project_to_image(part, cam, cfg)[0], cam.image_size, cfg, world,
+                                       all_reduce=(mode == 'sharded'))
+    log(f"[{mode}] tile-row bounds {bounds}")
   if mode == 'sharded':
     # every rank generated the same scene (same seed); it keeps only its shard of the gaussians
     shard_begin, shard_end = shard_range(args.n, world, rank)
@@ -238,10 +250,10 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
       t.grad = None
     if mode == 'sharded':
       render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
-                          backward=not args.forward_only, index_offset=shard_begin, comm_stats=comm)
+                          backward=not args.forward_only, index_offset=shard_begin, comm_stats=comm, bounds=bounds)
     elif mode == 'strips':
       render_strip_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
-                        backward=not args.forward_only, comm_stats=comm)
+                        backward=not args.forward_only, comm_stats=comm, bounds=bounds)
     elif args.forward_only:
       with torch.no_grad():
         render_gaussians(g, cam, cfg, use_sh=True)
@@ -320,6 +332,7 @@ def main():
     ms = elapsed / args.steps * 1e3
     log(f"[{mode}] timed {args.steps} steps: {ms:.3f} ms/step")
     runs[mode] = {"ms_per_step": round(ms, 3), "value": round(args.n / (ms * 1e-3) / 1e6, 2),
+                  "strips": "even tile rows" if args.even_strips or world == 1 else "overlap-balanced",
                   "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
                   "rank0_exchange_bytes_per_step": comm or None}
     if mode != modes[-1]:

@@ -53,12 +53,22 @@ def strip_rows(tiles_high: int, world_size: int, rank: int,
 
 def allreduce_boundary_grads(grad_points: torch.Tensor, grad_features: torch.Tensor,
                              group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-  """Sum the per-gaussian 2D-boundary gradients over all strips with a single collective."""
+  """Sum the per-gaussian 2D-boundary gradients [d gaussians2d | d colour] (40 B per visible gaussian for RGB)
+  over all strips: reduce-scatter + all-gather of ONE buffer.  On the fully connected xGMI fabric both halves are
+  direct exchanges that keep all 7 links of a GPU busy with 1/N-sized pieces, and a rank holds its
+  reduced shard between the two calls.  Rows are padded to a multiple of the world size."""
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
     return grad_points, grad_features
-  buf = torch.cat([grad_points, grad_features], dim=1).contiguous()
-  dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-  return buf[:, :grad_points.shape[1]], buf[:, grad_points.shape[1]:]
+  world = dist.get_world_size(group)
+  n, width = grad_points.shape[0], grad_points.shape[1] + grad_features.shape[1]
+  rows = (n + world - 1) // world * world
+  buf = grad_points.new_zeros((rows, width)) if rows != n else grad_points.new_empty((rows, width))
+  buf[:n, :grad_points.shape[1]] = grad_points
+  buf[:n, grad_points.shape[1]:] = grad_features
+  shard = buf.new_empty((rows // world, width))
+  dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group)
+  dist.all_gather_into_tensor(buf, shard, group=group)
+  return buf[:n, :grad_points.shape[1]], buf[:n, grad_points.shape[1]:]
 
 
 def _tie_to_exchange(loss: torch.Tensor, g2: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
@@ -79,8 +89,13 @@ def _tie_to_exchange(loss: torch.Tensor, g2: torch.Tensor, f2: torch.Tensor) -> 
 def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
                       loss_fn: Callable[[torch.Tensor, Tuple[int, int]], torch.Tensor],
                       use_sh: bool = False, rank: Optional[int] = None, world_size: Optional[int] = None,
-                      group=None, backward: bool = True, comm_stats: Optional[dict] = None):
+                      group=None, backward: bool = True, comm_stats: Optional[dict] = None,
+                      bounds: Optional[Sequence[int]] = None):
   """One forward(+backward) step of the strip-sharded renderer on this rank.
+
+  ``bounds`` = [b_0 = 0, ..., b_world = tiles_high]: rank r renders tile rows [b_r, b_{r+1}) (default: even
+  split).  ``overlap_balanced_bounds`` derives them from the per-tile-row overlap histogram; the gaussians are
+  replicated, so every rank computes the same bounds without communicating.
 
   ``comm_stats`` (optional dict) receives the bytes this rank contributes to the collective per step.
 
@@ -111,7 +126,7 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
 
   ts = config.tile_size
   tiles_high = (camera_params.image_size[1] + ts - 1) // ts
-  rows = strip_rows(tiles_high, world_size, rank)
+  rows = strip_rows(tiles_high, world_size, rank) if bounds is None else (int(bounds[rank]), int(bounds[rank + 1]))
   rendering = render_projected(indexes, g2, f2, depths.detach(), camera_params, config, tile_rows=rows)
 
   px_rows = (rows[0] * ts, min(rows[1] * ts, camera_params.image_size[1]))
@@ -123,7 +138,7 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
     gf = f2.grad if f2.grad is not None else torch.zeros_like(f2)
     gp, gf = allreduce_boundary_grads(gp, gf, group)
     if comm_stats is not None:
-      comm_stats['all_reduce_bytes'] = (gp.shape[1] + gf.shape[1]) * gp.shape[0] * gp.element_size()
+      comm_stats['reduce_scatter_plus_all_gather_buffer_bytes'] = (gp.shape[1] + gf.shape[1]) * gp.shape[0] * gp.element_size()
     tensors, grads = [], []
     if gaussians2d.requires_grad:
       tensors.append(gaussians2d); grads.append(gp)
@@ -453,6 +468,38 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
     if config.compute_point_heuristic:
       point_stats['point_heuristic'] = full[:, k:k + 2]
   return rendering, loss.detach()
+
+
+def overlap_balanced_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, int], config: RasterConfig,
+                            world_size: int, group=None, all_reduce: bool = False):
+  """Strip boundaries that equalise the number of (tile, gaussian) OVERLAPS per strip — the work of the mapper
+  and both raster passes — instead of the number of tile rows: per-tile-row histogram of each splat's tile span
+  (rows x columns of the mapper's bounding-box query; the oriented-box test removes a near-constant fraction).
+  Replicated gaussians need no communication (``all_reduce=False``: every rank computes the same histogram); for
+  sharded gaussians the histograms are summed with one small all-reduce.  One host read of ``tiles_high`` floats:
+  meant to be called every few frames, not inside the timed step."""
+  ts = float(config.tile_size)
+  tiles_high = (image_size[1] + config.tile_size - 1) // config.tile_size
+  tiles_wide = (image_size[0] + config.tile_size - 1) // config.tile_size
+  p = gaussians2d.detach()
+  mx, my, ax, ay, sx, sy, alpha = (p[:, i] for i in range(7))
+  gs = torch.sqrt(2.0 * torch.log(alpha / config.alpha_threshold))
+  ex = torch.sqrt((ax * sx * gs) ** 2 + (ay * sy * gs) ** 2)
+  ey = torch.sqrt((ay * sx * gs) ** 2 + (ax * sy * gs) ** 2)
+  ok = torch.isfinite(ex) & torch.isfinite(ey)
+  cols = (torch.ceil((mx + ex) / ts).clamp(0, tiles_wide) - torch.floor((mx - ex) / ts).clamp(0, tiles_wide)).clamp(min=1)
+  lo = torch.floor((my - ey) / ts).clamp(0, tiles_high - 1)
+  hi = torch.ceil((my + ey) / ts).clamp(1, tiles_high)
+  hi = torch.maximum(hi, lo + 1)
+  weight = torch.where(ok, cols, torch.zeros_like(cols))
+  # difference array: +cols at lo, -cols at hi, then a prefix sum gives overlaps per tile row
+  diff = torch.zeros((tiles_high + 1,), dtype=torch.float32, device=p.device)
+  diff.index_add_(0, lo.to(torch.int64), weight.float())
+  diff.index_add_(0, hi.to(torch.int64), -weight.float())
+  hist = torch.cumsum(diff, 0)[:tiles_high]
+  if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_reduce(hist, group=group)
+  return strip_bounds(tiles_high, world_size, hist.clamp(min=0).tolist())
 
 
 def balanced_strip_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, int], config: RasterConfig,

@@ -73,13 +73,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_strip_backward_allreduce():
-  world = 2
+@pytest.mark.parametrize('world', [2, 3])      # 700 rows: divisible by 2, padded for 3 (reduce-scatter + all-gather)
+def test_strip_backward_reduce_scatter_all_gather(world):
   port = _free_port()
   mgr = mp.Manager()
   ret = mgr.dict()
   mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-  assert dict(ret) == {0: True, 1: True}
+  assert dict(ret) == {r: True for r in range(world)}
 
 
 # ---- gaussian-sharded + strip-sharded path: routing and the all-to-all exchange (gloo) -----------
@@ -205,3 +205,29 @@ def test_constant_loss_rank_still_joins_reverse_exchange():
   ret = mgr.dict()
   mp.spawn(_constant_loss_worker, args=(world, port, ret), nprocs=world, join=True)
   assert dict(ret) == {r: True for r in range(world)}
+
+
+def test_overlap_balanced_bounds_follow_the_work():
+  from oracle import mapper as omap
+  from taichi_splatting_amd import RasterConfig
+  from taichi_splatting_amd.distributed import overlap_balanced_bounds
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  torch.manual_seed(0)
+  size = (256, 512)                                     # 32 tile rows
+  g = random_2d_gaussians(6000, size, scale_factor=1.5)
+  g.position[:, 1] = g.position[:, 1] ** 2 / size[1]    # crowd the splats towards the top of the image
+  p = project_gaussians2d(g)
+  cfg = RasterConfig()
+  for world in (1, 2, 4, 8):
+    bounds = overlap_balanced_bounds(p, size, cfg, world)
+    assert bounds[0] == 0 and bounds[-1] == 32 and len(bounds) == world + 1
+    assert all(a <= b for a, b in zip(bounds[:-1], bounds[1:]))
+  bounds = overlap_balanced_bounds(p, size, cfg, 4)
+  # true overlaps per strip (oracle mapper) are far better balanced than with even strips
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy(), g.depths.numpy(), size, 16)
+  per_row = (ranges[..., 1] - ranges[..., 0]).sum(axis=1)
+  work = lambda b: [int(per_row[b[i]:b[i + 1]].sum()) for i in range(len(b) - 1)]
+  balanced, even = work(bounds), work([0, 8, 16, 24, 32])
+  assert max(balanced) < 0.6 * max(even), (balanced, even)
+  assert max(balanced) < 1.35 * (sum(balanced) / 4), balanced
