@@ -6,14 +6,16 @@ Each configuration is checked twice:
     sizes gaussians as width / sqrt(n) pixels, so n / pixels fixed keeps the per-tile population), float32, on
     a GATE-STABLE scene: gaussians with a (pixel, splat) pair closer than 1e-4 (relative) to the blend gate
     alpha > alpha_threshold are removed first (oracle.raster.gate_margin), so no float32 rounding can flip a
-    gate.  Pixels and the gradients at the 2D boundary (d gaussians2d, d colour) must then agree with the
-    float64 oracle to the 1e-4 of BASELINE.json's north_star EVERYWHERE, with no quantile or absolute slack.
+    gate.  Pixels must then agree with the float64 oracle pipeline to the 1e-4 of BASELINE.json's north_star
+    EVERYWHERE, and so must the gradients at the 2D boundary (d gaussians2d, d colour) against the oracle
+    rasterizer evaluated on the SAME float32 splats the kernels rasterized (the float32 projection perturbs the
+    splat parameters by ~1e-6, a near-isotropic splat's axis by more: the rasterizer is judged on its inputs).
     The gradients of the 3D parameters go through the projection backward, whose float32 evaluation is
     ill-conditioned for some gaussians in ANY implementation of the reference's formulas (eigen-decomposition of
     a near-isotropic blurred covariance, quaternion normalisation): torch_lib's own arithmetic run in float32 is
-    off by up to ~10 % of the largest gradient on such rows.  They are therefore held to (a) 1e-4 of the largest
-    gradient on every row where the oracle evaluated in float32 is itself accurate, and (b) a worst-row error no
-    larger than twice the float32 oracle's own (tests/test_gpu_projection_sh.py states the criterion);
+    off by 1e-3 ... 1e+3 times the largest gradient on such rows.  They are held to 1e-4 on >= 99 % of the
+    gaussians and everywhere to the accuracy of the oracle evaluated in float32
+    (tests/test_gpu_projection_sh.py::assert_f32_gradient_as_accurate_as_reference states the criterion);
   * at full size through size-independent properties: mapper invariants, the float32 product kernels against
     the float64 generic kernels on the same tile lists, tile-row strips composing to the full frame in image and
     in gradient, finite gradients."""
@@ -113,8 +115,16 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   r.points.gaussians2d.retain_grad()
   r.points.features.retain_grad()
   (r.image * G.to(DEV).float()).sum().backward()
-  # 2D boundary: strict
-  for k, got, w in (('gaussians2d', r.points.gaussians2d.grad, want['grad_points']), ('features', r.points.features.grad, want['grad_feats'])):
+  # 2D boundary: the oracle rasterizer on the kernels' own float32 splats and tile lists, strict
+  p_h, f_h = r.points.gaussians2d.detach().cpu().double(), r.points.features.detach().cpu().double()
+  o2p_h, ranges_h = omap.map_to_tiles(p_h.numpy().astype(np.float32), oproj.ndc_depth(r.points.depths.detach().cpu().double(), *cam.depth_range).numpy().astype(np.float32),
+                                      size, cfg.tile_size, cfg.alpha_threshold)[:2]
+  o2p_h, ranges_h = torch.from_numpy(o2p_h), torch.from_numpy(ranges_h)
+  assert float(orast.gate_margin(p_h, ranges_h, o2p_h, size, cfg).min()) > 1e-5        # still gate-stable
+  img_h, _, _ = orast.forward(p_h, f_h, ranges_h, o2p_h, size, cfg)
+  gp_h, gf_h, _ = orast.backward(p_h, f_h, ranges_h, o2p_h, img_h, G, size, cfg)
+  assert (r.image.detach().cpu().double() - img_h).abs().max() < 1e-4
+  for k, got, w in (('gaussians2d', r.points.gaussians2d.grad, gp_h), ('features', r.points.features.grad, gf_h)):
     scale = w.abs().max().item()
     assert (got.cpu().double() - w).abs().max() < 1e-4 * scale, (name, k, (got.cpu().double() - w).abs().max().item(), scale)
   # 3D parameters: see the module docstring
