@@ -33,10 +33,14 @@ DETERMINISTIC_BACKWARD = os.environ.get('MS_DETERMINISTIC', '0') not in ('0', ''
 
 
 def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
-  """Product path (float32 RGB, plain pdf): csrc/raster_bwd_scan.hip.  ``MS_RASTER_BWD=patch`` selects the
-  pixel-per-lane kernels of raster_fast.hip instead (A/B measurements only)."""
-  return (dtype == torch.float32 and f == 3 and not config.antialias
-          and os.environ.get('MS_RASTER_BWD', 'scan') != 'patch')
+  """Product path (float32 RGB, plain pdf, tile 8 / 16): the splat-per-lane scan kernel of csrc/raster_bwd_scan.hip
+  (config D: 1.64 ms at tile 16, 1.82 ms at tile 8).  At tile 32 a wave's 8x8 patch sees only ~1/16 of the
+  staged splats, the per-sub-patch lists stay short and the pixel-per-lane kernel of raster_fast.hip is faster
+  (3.1 vs 4.4 ms), so it keeps that tile size — and the deterministic mode, which only the scan kernel has, is
+  the exception.  ``MS_RASTER_BWD=patch`` forces the pixel-per-lane kernels (A/B measurements)."""
+  if dtype != torch.float32 or f != 3 or config.antialias or os.environ.get('MS_RASTER_BWD', 'scan') == 'patch':
+    return False
+  return config.tile_size <= 16 or DETERMINISTIC_BACKWARD
 
 
 def _tile_rows(config: RasterConfig, image_size, tile_rows):
