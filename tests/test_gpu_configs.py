@@ -69,26 +69,33 @@ def oracle_frame(g, cam, cfg, G):
   return out
 
 
-def oracle_leaf_grads_f32(g, cam, cfg, grad_points, grad_feats):
-  """The projection / SH backward of the oracle evaluated in float32 (torch CPU), fed with the float64 oracle's
-  2D-boundary gradients: what torch_lib's own arithmetic yields at the precision the product runs in."""
-  g, cam = g.to(dtype=torch.float32), cam.to(dtype=torch.float32)
+def oracle_leaf_grads(g, cam, cfg, grad_points, grad_feats, dtype):
+  """The projection / SH backward of the oracle in ``dtype`` (torch CPU) for given 2D-boundary gradients: float64
+  = the exact chain, float32 = what torch_lib's own arithmetic yields at the precision the product runs in."""
+  g, cam = g.to(dtype=dtype), cam.to(dtype=dtype)
   leaves = [getattr(g, k).detach().clone().requires_grad_(True) for k in LEAVES]
   pos, ls, rot, al, feat = leaves
   points, depths, idx = oproj.apply(pos, ls, rot, al, cam.T_camera_world, cam.projection, cam.image_size,
                                     cam.depth_range, cfg.blur_cov, cfg.clamp_margin, cfg.alpha_threshold)
   feats = osh.evaluate_sh_at(feat, pos.detach(), idx, torch.inverse(cam.T_camera_world)[0:3, 3])
-  torch.autograd.backward([points, feats], [grad_points.float(), grad_feats.float()])
+  torch.autograd.backward([points, feats], [grad_points.to(dtype), grad_feats.to(dtype)])
   return idx, [x.grad.double() for x in leaves]
 
 
-def gate_stable(g, cam, cfg, rel_margin=1e-4):
-  """Drop the gaussians whose projected splat has a pixel within ``rel_margin`` of the blend gate."""
+def gate_stable(g, cam, cfg, rel_margin=3e-3):
+  """Drop the gaussians whose projected splat has a pixel within ``rel_margin`` of the blend gate, judged on BOTH
+  the float64 oracle's splats and the float32 splats the kernels produce (the float32 projection moves alpha * g
+  by ~1e-6 relative in general and by up to ~1e-3 for nearly isotropic splats, whose axis is ill-conditioned)."""
   o = oracle_frame(g, cam, cfg, None)
-  margin = orast.gate_margin(o['points'], o['ranges'], o['o2p'], cam.image_size, cfg)
   keep = torch.ones(g.position.shape[0], dtype=torch.bool)
+  margin = orast.gate_margin(o['points'], o['ranges'], o['o2p'], cam.image_size, cfg)
   keep[o['idx'][margin < rel_margin]] = False
-  assert keep.float().mean() > 0.8
+  with torch.no_grad():
+    p32, d32, idx32 = project_to_image(g.to(DEV), cam.to(device=DEV), cfg)
+    o2p32, ranges32 = map_to_tiles(p32, ndc_depth(d32, cam.near_plane, cam.far_plane), cam.image_size, cfg)
+  margin32 = orast.gate_margin(p32.cpu().double(), ranges32.cpu(), o2p32.cpu(), cam.image_size, cfg)
+  keep[idx32.cpu()[margin32 < rel_margin]] = False
+  assert keep.float().mean() > 0.6
   return g[keep]
 
 
@@ -123,18 +130,21 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   o2p_h, ranges_h = omap.map_to_tiles(p_h.numpy().astype(np.float32), oproj.ndc_depth(r.points.depths.detach().cpu().double(), *cam.depth_range).numpy().astype(np.float32),
                                       size, cfg.tile_size, cfg.alpha_threshold)[:2]
   o2p_h, ranges_h = torch.from_numpy(o2p_h), torch.from_numpy(ranges_h)
-  assert float(orast.gate_margin(p_h, ranges_h, o2p_h, size, cfg).min()) > 1e-5        # still gate-stable
+  assert float(orast.gate_margin(p_h, ranges_h, o2p_h, size, cfg).min()) > 1e-4        # gate-stable on the kernels' inputs
   img_h, _, _ = orast.forward(p_h, f_h, ranges_h, o2p_h, size, cfg)
   gp_h, gf_h, _ = orast.backward(p_h, f_h, ranges_h, o2p_h, img_h, G, size, cfg)
   assert (r.image.detach().cpu().double() - img_h).abs().max() < 1e-4
   for k, got, w in (('gaussians2d', r.points.gaussians2d.grad, gp_h), ('features', r.points.features.grad, gf_h)):
     scale = w.abs().max().item()
     assert (got.cpu().double() - w).abs().max() < 1e-4 * scale, (name, k, (got.cpu().double() - w).abs().max().item(), scale)
-  # 3D parameters: see the module docstring
-  idx32, ref32 = oracle_leaf_grads_f32(g, cam, cfg, want['grad_points'], want['grad_feats'])
-  assert torch.equal(idx32, want['idx'])
+  # 3D parameters: the projection / SH backward stage, fed with the kernels' own 2D-boundary gradients in all
+  # three evaluations (kernels, float64 oracle chain, float32 oracle chain); see the module docstring
+  gp_k, gf_k = r.points.gaussians2d.grad.cpu().double(), r.points.features.grad.cpu().double()
+  idx64, ref64 = oracle_leaf_grads(g, cam, cfg, gp_k, gf_k, torch.float64)
+  idx32, ref32 = oracle_leaf_grads(g, cam, cfg, gp_k, gf_k, torch.float32)
+  assert torch.equal(idx32, want['idx']) and torch.equal(idx64, want['idx'])
   from .test_gpu_projection_sh import assert_f32_gradient_as_accurate_as_reference
-  for k, w64, w32 in zip(LEAVES, want['grads'], ref32):
+  for k, w64, w32 in zip(LEAVES, ref64, ref32):
     assert_f32_gradient_as_accurate_as_reference(getattr(gd, k).grad.cpu(), w64, w32, (name, k))
 
 
