@@ -5,8 +5,9 @@
 //   * segmented pair sort (cub::DeviceSegmentedSort::SortPairs, segmented_sort_pairs.cu:9-73;
 //     not on the render path — kept for API parity)
 //
-// Radix pass = upsweep (per-block digit histogram) -> scan of the digit-major histogram ->
-// downsweep (stable in-block ranking with wave64 ballots, then scatter).  Block item order is
+// Radix pass = upsweep (per-block digit histogram) -> one workgroup per digit scans its row of the digit-major
+// histogram (the 256 digit totals are scanned by every downsweep block itself) -> downsweep (stable in-block
+// ranking with wave64 ballots, then scatter): three launches.  Block item order is
 // wave-major, round-major, lane-minor, so loads are fully coalesced and stability only needs
 // (earlier waves) + (earlier rounds of this wave) + (lower lanes of this round).
 #include "common.h"
@@ -195,11 +196,31 @@ radix_upsweep_kernel(const KeyT* __restrict__ keys, int64_t n, int shift, unsign
   }
 }
 
+// One workgroup per digit: exclusive scan of that digit's per-block counts (row d of the digit-major histogram)
+// in place, and the digit's total.  Together with the 256-entry scan of the totals that every downsweep block does
+// for itself, this replaces the general two-launch scan of the whole 256 x blocks table per radix pass.
+__global__ void __launch_bounds__(SCAN_THREADS)
+radix_row_scan_kernel(int32_t* __restrict__ hist, int64_t num_blocks, int32_t* __restrict__ digit_totals) {
+  __shared__ int lds[4];
+  int32_t* row = hist + (int64_t)blockIdx.x * num_blocks;
+  int carry = 0;
+  for (int64_t base = 0; base < num_blocks; base += SCAN_THREADS) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < num_blocks ? row[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, &total);
+    if (i < num_blocks) row[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
+}
+
 template <typename KeyT>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
                        KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
-                       unsigned mask, const int32_t* __restrict__ hist_scanned, int64_t num_blocks) {
+                       unsigned mask, const int32_t* __restrict__ hist_scanned,
+                       const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
   __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
@@ -266,7 +287,11 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
       run += c;
     }
     s_digit_local[d] = local;
-    s_digit_global[d] = (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
+    // global start of the digit = items of all smaller digits (256-entry scan, done by every block for itself)
+    // + items of this digit in earlier blocks (radix_row_scan_kernel)
+    int all_items;
+    const unsigned digit_base = (unsigned)block_exclusive_scan(digit_totals[d], s_scan, &all_items);
+    s_digit_global[d] = digit_base + (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
   }
   __syncthreads();
 
@@ -315,7 +340,7 @@ static SortTmp sort_tmp_layout(int64_t n, int key_bytes) {
   SortTmp t;
   size_t off = 0;
   t.hist_off = off; off += align_up((size_t)(RS_RADIX * blocks + 1) * sizeof(int32_t), 256);
-  t.scan_off = off; off += scan_tmp_bytes(RS_RADIX * blocks);
+  t.scan_off = off; off += align_up((size_t)RS_RADIX * sizeof(int32_t), 256);      // digit totals
   t.keys_off = off; off += align_up((size_t)n * key_bytes, 256);
   t.vals_off = off; off += align_up((size_t)n * sizeof(int32_t), 256);
   t.total = off;
@@ -329,7 +354,7 @@ static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, Ke
   const int64_t blocks = div_up(n, RS_TILE);
   const SortTmp lay = sort_tmp_layout(n, sizeof(KeyT));
   int32_t* hist = (int32_t*)(tmp + lay.hist_off);
-  void* scan_tmp = tmp + lay.scan_off;
+  int32_t* digit_totals = (int32_t*)(tmp + lay.scan_off);       // 256 ints
   KeyT* keys_alt = (KeyT*)(tmp + lay.keys_off);
   int32_t* vals_alt = (int32_t*)(tmp + lay.vals_off);
 
@@ -349,9 +374,9 @@ static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, Ke
     int32_t* dst_v = to_out ? vals_out : vals_alt;
 
     radix_upsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(src_k, n, shift, mask, hist, blocks);
-    exclusive_scan_i32(hist, RS_RADIX * blocks, hist, nullptr, scan_tmp, s);
+    radix_row_scan_kernel<<<dim3(RS_RADIX), dim3(SCAN_THREADS), 0, s>>>(hist, blocks, digit_totals);
     radix_downsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(
-        src_k, src_v, dst_k, dst_v, n, shift, mask, hist, blocks);
+        src_k, src_v, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
     src_k = dst_k;
     src_v = dst_v;
   }
