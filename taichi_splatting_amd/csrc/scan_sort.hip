@@ -45,16 +45,41 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds /*>= 4 ints*
   return wave_off + incl - v;
 }
 
+// a thread's SCAN_ITEMS consecutive ints: four 128-bit loads when the tile is complete and aligned
+__device__ __forceinline__ void load_items(const int32_t* __restrict__ in, int64_t base, int64_t n, int (&vals)[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(in + base) & 15) == 0) {
+    const int4* p = reinterpret_cast<const int4*>(in + base);
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS / 4; ++q) {
+      const int4 v = p[q];
+      vals[4 * q] = v.x; vals[4 * q + 1] = v.y; vals[4 * q + 2] = v.z; vals[4 * q + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) vals[k] = base + k < n ? in[base + k] : 0;
+  }
+}
+
+__device__ __forceinline__ void store_items(int32_t* __restrict__ out, int64_t base, int64_t n, const int (&vals)[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(out + base) & 15) == 0) {
+    int4* p = reinterpret_cast<int4*>(out + base);
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS / 4; ++q) p[q] = make_int4(vals[4 * q], vals[4 * q + 1], vals[4 * q + 2], vals[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) if (base + k < n) out[base + k] = vals[k];
+  }
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ block_sums) {
   __shared__ int lds[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int items[SCAN_ITEMS];
+  load_items(in, base, n, items);
   int s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const int64_t i = base + k;
-    if (i < n) s += in[i];
-  }
+  for (int k = 0; k < SCAN_ITEMS; ++k) s += items[k];
   int total;
   block_exclusive_scan(s, lds, &total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -86,21 +111,19 @@ scan_downsweep_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* 
   __shared__ int lds[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int vals[SCAN_ITEMS];
+  load_items(in, base, n, vals);
   int s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const int64_t i = base + k;
-    vals[k] = i < n ? in[i] : 0;
-    s += vals[k];
-  }
+  for (int k = 0; k < SCAN_ITEMS; ++k) s += vals[k];
   int total;
   int prefix = block_exclusive_scan(s, lds, &total) + block_offsets[blockIdx.x];
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const int64_t i = base + k;
-    if (i < n) out[i] = prefix;
-    prefix += vals[k];
+  for (int k = 0; k < SCAN_ITEMS; ++k) {       // vals[k] <- exclusive prefix of item k
+    const int v = vals[k];
+    vals[k] = prefix;
+    prefix += v;
   }
+  store_items(out, base, n, vals);
 }
 
 // Two-launch variant for up to SCAN_SELF_MAX_BLOCKS tiles: every block sums the totals of the tiles before
@@ -119,21 +142,19 @@ scan_downsweep_self_kernel(const int32_t* __restrict__ in, int64_t n, const int3
 
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int vals[SCAN_ITEMS];
+  load_items(in, base, n, vals);
   int s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const int64_t i = base + k;
-    vals[k] = i < n ? in[i] : 0;
-    s += vals[k];
-  }
+  for (int k = 0; k < SCAN_ITEMS; ++k) s += vals[k];
   int total;
   int prefix = block_exclusive_scan(s, lds, &total) + block_prefix;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    const int64_t i = base + k;
-    if (i < n) out[i] = prefix;
-    prefix += vals[k];
+  for (int k = 0; k < SCAN_ITEMS; ++k) {       // vals[k] <- exclusive prefix of item k
+    const int v = vals[k];
+    vals[k] = prefix;
+    prefix += v;
   }
+  store_items(out, base, n, vals);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     out[n] = block_prefix + total;
     if (total_host) *total_host = block_prefix + total;

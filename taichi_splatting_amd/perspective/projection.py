@@ -18,6 +18,22 @@ from ..data_types import Gaussians3D, RasterConfig
 from .params import CameraParams
 
 
+_all_indexes = {}
+
+
+def _identity_indexes(n: int, device: torch.device) -> torch.Tensor:
+  """arange(n) int64 for the "every gaussian is visible" case, kept per (device, n): it is built right after the
+  host synchronisation on the visible count, when the launch queue is empty and every extra launch is exposed
+  latency (48 MB of writes at 6 M gaussians).  Callers treat ``indexes`` as read-only (it is marked
+  non-differentiable and only ever indexed with)."""
+  key = (device.type, device.index, n)
+  cached = _all_indexes.get(key)
+  if cached is None:
+    _all_indexes.clear()                  # one scene at a time: do not hoard 8 B per gaussian per size
+    cached = _all_indexes[key] = torch.arange(n, dtype=torch.int64, device=device)
+  return cached
+
+
 def _project_forward(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
                      image_size, depth_range, blur_cov, clamp_margin, alpha_threshold, with_ndc=False):
   lib = _lib.load()
@@ -51,7 +67,7 @@ def _project_forward(position, log_scaling, rotation, alpha_logit, T_camera_worl
 
   if v == n and not with_ndc:
     # every gaussian is visible: the uncompacted arrays ARE the result, no gather pass
-    return points_full, depth_full.unsqueeze(1), torch.arange(n, dtype=torch.int64, device=device), None
+    return points_full, depth_full.unsqueeze(1), _identity_indexes(n, device), None
 
   points = torch.empty((v, 7), dtype=dtype, device=device)
   depth = torch.empty((v, 1), dtype=dtype, device=device)

@@ -41,11 +41,14 @@ def render_gaussians(
     render_median_depth: extra quantile pass producing ``median_depth_image``
     tile_rows: optional (begin, end) tile-row strip to render (multi-GPU sharding)
   """
+  # launched before the projection's host synchronisation (visible count) so that the first kernel queued after it
+  # is the long SH pass, not a string of small ones
+  camera_position = camera_params.camera_position if use_sh else None
   gaussians2d, depths, indexes = project_to_image(gaussians, camera_params, config)
 
   if use_sh:
     features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes,
-                              camera_params.camera_position, unique_indexes=True)
+                              camera_position, unique_indexes=True)
   else:
     features = gaussians.feature[indexes]
     assert len(features.shape) == 2, f"Features must be (N, C) if use_sh=False, got {features.shape}"
