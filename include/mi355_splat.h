@@ -79,7 +79,7 @@ int ms_project_gather(const void* points7, const void* depth, const int32_t* fla
 /* ms_project_bwd replaces indexed_project_kernel.grad (projection.py:85-119,167-188): hand-derived
  * reverse mode.  Rows indexes[i] of the N-sized outputs are WRITTEN (rows of culled gaussians are
  * left untouched: pre-zero them); grad_camera (16 values: dT[3][4] row-major then d[fx,fy,cx,cy])
- * is ACCUMULATED atomically and may be NULL. */
+ * is ACCUMULATED atomically and may be NULL; grad_depth may be NULL (no gradient reaches the depth output). */
 int ms_project_bwd(const void* position, const void* log_scaling, const void* rotation,
                    const void* alpha_logit, const void* T_camera_world, const void* projection,
                    int image_w, int image_h, double blur_cov, double clamp_margin,

@@ -99,7 +99,7 @@ project_bwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
     for (int k = 0; k < 7; ++k) gp[k] = g_points[i * 7 + k];
 
     T dp[3], dls[3], dq[4], dal;
-    project_backward(p, cam, st, gp, g_depth[i], dp, dls, dq, dal, cam_grad);
+    project_backward(p, cam, st, gp, g_depth ? g_depth[i] : T(0), dp, dls, dq, dal, cam_grad);
 
 #pragma unroll
     for (int k = 0; k < 3; ++k) d_position[idx * 3 + k] = dp[k];
@@ -193,7 +193,7 @@ extern "C" int ms_project_bwd(const void* position, const void* log_scaling, con
   if (v == 0) return 0;
   MS_CHECK_ARG(position && log_scaling && rotation && alpha_logit && T_camera_world && projection && indexes,
                "null input");
-  MS_CHECK_ARG(grad_points7 && grad_depth, "null incoming gradient");
+  MS_CHECK_ARG(grad_points7 != nullptr, "null incoming gradient");   // grad_depth may be NULL (= zeros)
   MS_CHECK_ARG(grad_position && grad_log_scaling && grad_rotation && grad_alpha_logit, "null output");
   int64_t blocks = div_up(v, 256);
   if (grad_camera && blocks > 2048) blocks = 2048;       // bounded atomic count for the camera sums

@@ -94,6 +94,7 @@ class _ProjectFunction(torch.autograd.Function):
 
     points, depth, indexes, _ = _project_forward(*tensors, image_size, depth_range, blur_cov,
                                                  clamp_margin, alpha_threshold)
+    ctx.set_materialize_grads(False)      # no zero tensors for outputs the loss does not touch (depth, indexes)
     ctx.image_size = image_size
     ctx.blur_cov, ctx.clamp_margin = blur_cov, clamp_margin
     ctx.indexes = indexes
@@ -118,14 +119,16 @@ class _ProjectFunction(torch.autograd.Function):
     need_camera = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
     grad_camera = torch.zeros((16,), dtype=dtype, device=device) if need_camera else None
 
+    if dpoints is None and ddepth is None:
+      return (None,) * 11
     if v > 0:
-      dpoints = dpoints.contiguous()
-      ddepth = ddepth.contiguous()
+      dpoints = dpoints.contiguous() if dpoints is not None else torch.zeros((v, 7), dtype=dtype, device=device)
+      ddepth = ddepth.contiguous() if ddepth is not None else None
       _lib.check(lib.ms_project_bwd(position.data_ptr(), log_scaling.data_ptr(), rotation.data_ptr(),
                                     alpha_logit.data_ptr(), T_camera_world.data_ptr(), projection.data_ptr(),
                                     int(ctx.image_size[0]), int(ctx.image_size[1]), float(ctx.blur_cov),
                                     float(ctx.clamp_margin), indexes.data_ptr(), v, dpoints.data_ptr(),
-                                    ddepth.data_ptr(), grad_position.data_ptr(), grad_log_scaling.data_ptr(),
+                                    _lib.ptr(ddepth), grad_position.data_ptr(), grad_log_scaling.data_ptr(),
                                     grad_rotation.data_ptr(), grad_alpha_logit.data_ptr(), _lib.ptr(grad_camera),
                                     _lib.dtype_code(dtype), _lib.current_stream(device)), "project_to_image backward")
 

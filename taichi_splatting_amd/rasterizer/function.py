@@ -140,6 +140,7 @@ class _RasterFunction(torch.autograd.Function):
           alpha = alpha_c
       image = torch.cat(images, dim=2)
 
+    ctx.set_materialize_grads(False)      # no zero tensors for image_weight / heuristics / visibility gradients
     ctx.overlap_to_point = o2p
     ctx.tile_overlap_ranges = ranges
     ctx.image_size = (w, h)
@@ -161,7 +162,7 @@ class _RasterFunction(torch.autograd.Function):
     need_points, need_features = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
 
     heuristic = ctx.point_heuristic if config.compute_point_heuristic else None
-    if not (need_points or need_features or heuristic is not None):
+    if grad_image is None or not (need_points or need_features or heuristic is not None):
       return None, None, None, None, None, None, None, None
     moments_path = _use_moments_backward(config, gaussians.dtype, f) and image.shape[0] > 0 and n > 0
     alloc = torch.empty_like if moments_path else torch.zeros_like   # the finalize pass stores, the others accumulate
