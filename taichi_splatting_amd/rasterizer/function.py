@@ -43,24 +43,6 @@ def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
   return config.tile_size <= 16 or DETERMINISTIC_BACKWARD
 
 
-_zero_streams = {}
-
-
-def _zeroed_on_side_stream(shape, dtype, device):
-  """A zero-filled buffer whose fill runs on a second HIP stream, concurrently with whatever the current stream
-  executes next (the forward raster kernel: VALU bound, HBM idle).  Returns (tensor, event to wait for before
-  use).  The backward pass needs 64 B per gaussian of zeroed accumulators (384 MB at 6 M gaussians, ~50 us of
-  memset if done in line)."""
-  key = (device.type, device.index)
-  side = _zero_streams.get(key)
-  if side is None:
-    side = _zero_streams[key] = torch.cuda.Stream(device=device)
-  with torch.cuda.stream(side):
-    buf = torch.zeros(shape, dtype=dtype, device=device)
-    ready = side.record_event()
-  return buf, ready
-
-
 def _tile_rows(config: RasterConfig, image_size, tile_rows):
   tiles_high = (image_size[1] + config.tile_size - 1) // config.tile_size
   if tile_rows is None:
@@ -159,11 +141,6 @@ class _RasterFunction(torch.autograd.Function):
       image = torch.cat(images, dim=2)
 
     ctx.set_materialize_grads(False)      # no zero tensors for image_weight / heuristics / visibility gradients
-    # accumulators of the backward pass, zeroed while the forward kernel runs
-    ctx.moments = None
-    if (any(ctx.needs_input_grad[:2]) and n > 0 and _use_moments_backward(config, dtype, f)
-        and os.environ.get('MS_ASYNC_ZERO', '1') != '0'):
-      ctx.moments = _zeroed_on_side_stream((n, _lib.MOMENT_ROW), torch.int64 if DETERMINISTIC_BACKWARD else torch.float32, device)
     ctx.overlap_to_point = o2p
     ctx.tile_overlap_ranges = ranges
     ctx.image_size = (w, h)
@@ -202,15 +179,7 @@ class _RasterFunction(torch.autograd.Function):
 
     if moments_path:
       det = int(DETERMINISTIC_BACKWARD)
-      want_dtype = torch.int64 if det else torch.float32
-      if ctx.moments is not None and ctx.moments[0].dtype == want_dtype:
-        moments, ready = ctx.moments
-        ctx.moments = None                 # single use: a second backward (retain_graph) zeroes a fresh buffer
-        current = torch.cuda.current_stream(gaussians.device)
-        current.wait_event(ready)
-        moments.record_stream(current)
-      else:
-        moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=want_dtype, device=gaussians.device)
+      moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.int64 if det else torch.float32, device=gaussians.device)
       _lib.check(lib.ms_raster_bwd_moments(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                            _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
                                            grad_image.data_ptr() - row_bytes * f, w, h, cfg_c, moments.data_ptr(), det,
