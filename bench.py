@@ -150,14 +150,14 @@ def stage_breakdown(g, cam, cfg, use_sh):
 
 def cpu_baseline(args):
   """The CPU oracle (torch restatement of the reference path; the reference has no CPU rasterizer)
-  timed on a bounded sample of the same workload family: 100k gaussians,
-  512x512, fwd+bwd (about 10 s of CPU work)."""
+  timed on a bounded sample of the same workload family at config D's density
+  (1.43 gaussians per pixel): 300k gaussians, 888x888, fwd+bwd (10-20 s of CPU work on 8 threads)."""
   import numpy as np
   from oracle import mapper as omap, projection as oproj, raster as orast, sh as osh
   from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
   from taichi_splatting_amd import RasterConfig
 
-  n, size = 100000, (512, 512)
+  n, size = 300000, (888, 888)
   torch.manual_seed(0)
   cam = random_camera(image_size=size)
   g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
