@@ -222,34 +222,38 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     // patch hits (one pass per batch unless most staged splats touch this 8x8 patch).
     int r = 0;
     while (r < count) {
-      // ---- cull: patch list + per sub-patch hit lists (depth order preserved) ---------------------------------
+      // ---- cull, level 1: the staged splats that can touch this wave's 8x8 patch -> patch list ------------------
       int pcount = 0;
-      int cnt[4] = {0, 0, 0, 0};
+      const float pcx = (float)patch_x + 4.0f, pcy = (float)patch_y + 4.0f;
       while (r < count) {
         const int j = r + lane;
-        const bool in = j < count;
+        const bool hit = j < count && scan_rect_hit(s_rec[j * 3 + 0], s_rec[j * 3 + 1], s_rec[j * 3 + 2], pcx, pcy, 3.5f);
+        const unsigned long long m = __ballot(hit);
+        const int nhit = __builtin_popcountll(m);
+        if (pcount + nhit > CAP) break;          // next pass (nhit <= 64 <= CAP: an empty list always takes the group)
+        const int ppos = pcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (hit) s_plist[wave][ppos] = (uint8_t)j;
+        pcount += nhit;
+        r += 64;
+      }
+      wave_lds_fence();
+      // ---- cull, level 2: only the patch hits (about 40 % of a batch) are tested against the four 4x4 sub-patches;
+      // both lists are appended in order, so they stay depth sorted
+      int cnt[4] = {0, 0, 0, 0};
+      for (int g = 0; g < pcount; g += 64) {
+        const int ppos = g + lane;
+        const bool in = ppos < pcount;
+        const int j = in ? (int)s_plist[wave][ppos] : 0;
         const float4 q0 = s_rec[j * 3 + 0], q1 = s_rec[j * 3 + 1], q2 = s_rec[j * 3 + 2];
-        bool hit[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
-          hit[q] = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
-        }
-        const bool any = hit[0] || hit[1] || hit[2] || hit[3];
-        const unsigned long long many = __ballot(any);
-        const int nany = __builtin_popcountll(many);
-        if (pcount + nany > CAP) break;          // next pass (nany <= 64 <= CAP: an empty list always takes the group)
-        const int ppos = pcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(many >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)many, 0u));
-        if (any) s_plist[wave][ppos] = (uint8_t)j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const unsigned long long m = __ballot(hit[q]);
+          const bool hit = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
+          const unsigned long long m = __ballot(hit);
           const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (hit[q]) s_list[wave][q][pos] = (uint8_t)ppos;
+          if (hit) s_list[wave][q][pos] = (uint8_t)ppos;
           cnt[q] += __builtin_popcountll(m);
         }
-        pcount += nany;
-        r += 64;
       }
       wave_lds_fence();
 #if MS_SCAN_ABLATE == 1
