@@ -135,7 +135,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                        FastParams rp, float* __restrict__ moments) {
   constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
   constexpr int BATCH = TS == 8 ? 128 : 256;     // splats staged per batch, shared by the tile's waves (uint8 indices)
-  constexpr int CAP = TS == 32 ? 96 : 128;   // patch hits a wave takes on per pass (>= 64: a pass always advances)
+  constexpr int CAP = TS == 32 ? 96 : (HEUR && TS == 16) ? 104 : 128;   // heuristics: 11 accumulators per row, keep four workgroups per CU   // patch hits a wave takes on per pass (>= 64: a pass always advances)
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= BATCH;   // one staged splat per thread, gathered one batch ahead
   // tile 16: 12 KB records + 1 KB ids + 4 x (4.5 KB accumulators + 0.6 KB lists + 1.25 KB pixels) = 38.5 KB: four
