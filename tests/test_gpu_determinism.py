@@ -46,3 +46,31 @@ def test_deterministic_backward_is_bitwise_repeatable(n, size, tile, monkeypatch
   for a, b in zip(runs[0], plain):
     scale = b.abs().max().item()
     assert (a - b).abs().max().item() <= 1e-4 * scale
+
+
+def test_deterministic_backward_dense_scene_with_heuristics(monkeypatch):
+  """Dense 2D scene (about 1500 splats per tile: several passes per staged batch in the backward kernel), point
+  heuristics on: the 2D gradients and heuristics are bitwise repeatable in deterministic mode."""
+  from taichi_splatting_amd import map_to_tiles, rasterize_with_tiles
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  torch.manual_seed(0)
+  size = (512, 384)
+  g = random_2d_gaussians(250_000, size, scale_factor=4.0, alpha_range=(0.75, 1.0), depth_range=(0.1, 100.)).to(DEV)
+  cfg = RasterConfig(compute_point_heuristic=True)
+  p, f = project_gaussians2d(g), g.feature.contiguous()
+  o2p, ranges = map_to_tiles(p, g.depths, size, cfg)
+  assert o2p.shape[0] / ranges[..., 0].numel() > 1000
+
+  def run():
+    pg, fg = p.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    out = rasterize_with_tiles(pg, fg, o2p, ranges.view(-1, 2), size, cfg)
+    out.image.sum().backward()
+    return pg.grad, fg.grad, out.point_heuristic.clone()
+  monkeypatch.setattr(raster_function, 'DETERMINISTIC_BACKWARD', True)
+  a, b = run(), run()
+  for x, y in zip(a, b):
+    assert torch.equal(x, y) and torch.isfinite(x).all() and float(x.abs().sum()) > 0
+  monkeypatch.setattr(raster_function, 'DETERMINISTIC_BACKWARD', False)
+  for x, y in zip(a, run()):
+    assert (x - y).abs().max().item() <= 1e-4 * y.abs().max().item()
