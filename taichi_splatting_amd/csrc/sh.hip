@@ -137,6 +137,22 @@ sh_bwd_params_kernel(const T* __restrict__ positions, const int64_t* __restrict_
   __builtin_amdgcn_wave_barrier();   // LDS traffic stays inside the wave: no block barrier needed
 
   const int row = f * D;
+  if (UNIQUE && D % 4 == 0 && f == 3 && sizeof(T) == 4) {
+    // RGB, degree 1 / 3, float: the wave's count x 3 x D gradient values leave as 128-bit stores, four consecutive
+    // coefficients of one (gaussian, channel) per lane — 1 KB per store instruction when the rows are adjacent
+    // (every gaussian visible), 16-byte pieces of the right rows otherwise.  The row-at-a-time loop below issues
+    // one 192-byte store instruction per gaussian.
+    constexpr int PIECES = 3 * D / 4;                       // 128-bit pieces per gaussian row
+    for (int q = lane; q < count * PIECES; q += 64) {
+      const int j = q / PIECES, k = q - j * PIECES;
+      const int c = (4 * k) / D, d0 = 4 * k - c * D;
+      const T g = s_g[wave][j * SH_MAX_F + c];
+      const T* y = &s_Y[wave][j * YS + d0];
+      float4 val = make_float4((float)(g * y[0]), (float)(g * y[1]), (float)(g * y[2]), (float)(g * y[3]));
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(g_params) + s_idx[wave][j] * row + 4 * k) = val;
+    }
+    return;
+  }
   for (int j = 0; j < count; ++j) {
     T* dst = g_params + s_idx[wave][j] * row;
     for (int e = lane; e < row; e += 64) {
