@@ -34,62 +34,6 @@ sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
   }
 }
 
-// RGB, degree 1 / 3, float: the forward as a coalesced stream.  Phase 1 (lane = gaussian) evaluates the basis into
-// LDS; phase 2 (lane = one 128-bit piece of a gaussian's 3 x D coefficients) loads the rows with 1 KB per load
-// instruction when they are adjacent, multiplies with the four matching basis values and sums the D / 4 pieces
-// of a channel over neighbouring lanes (quad DPP).  The thread-per-gaussian kernel above reads 192 B per lane
-// at a 192 B stride: every load instruction touches 64 different cache lines.
-template <int DEG>
-__global__ void __launch_bounds__(256)
-sh_fwd_rgb_kernel(const float* __restrict__ params, const float* __restrict__ positions,
-                  const int64_t* __restrict__ indexes, const float* __restrict__ cam_pos, int64_t v,
-                  float* __restrict__ out) {
-  constexpr int D = (DEG + 1) * (DEG + 1);
-  static_assert(D % 4 == 0, "pieces of four coefficients");
-  constexpr int YS = D + 1, ROW = 3 * D, PIECES = ROW / 4, PER_CHANNEL = D / 4;
-  __shared__ float s_Y[4][64 * YS];
-  __shared__ int64_t s_idx[4][64];
-
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64;
-  if (base >= v) return;
-  const int count = (v - base) < 64 ? (int)(v - base) : 64;
-  if (lane < count) {
-    const int64_t idx = indexes[base + lane];
-    const float dx = positions[idx * 3 + 0] - cam_pos[0];
-    const float dy = positions[idx * 3 + 1] - cam_pos[1];
-    const float dz = positions[idx * 3 + 2] - cam_pos[2];
-    const float len = t_sqrt(dx * dx + dy * dy + dz * dz);
-    float Y[D];
-    sh_basis<float, DEG>(dx / len, dy / len, dz / len, Y);
-#pragma unroll
-    for (int d = 0; d < D; ++d) s_Y[wave][lane * YS + d] = Y[d];
-    s_idx[wave][lane] = idx;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  const int total = count * PIECES;                                  // a multiple of 4: quads are all in or all out
-  for (int q0 = 0; q0 < total; q0 += 64) {
-    const int q = q0 + lane;
-    float partial = 0.0f;
-    int j = 0, k = 0;
-    if (q < total) {
-      j = q / PIECES; k = q - j * PIECES;
-      const float4 p = *reinterpret_cast<const float4*>(params + s_idx[wave][j] * ROW + 4 * k);
-      const float* y = &s_Y[wave][j * YS + 4 * (k % PER_CHANNEL)];
-      partial = p.x * y[0] + p.y * y[1] + p.z * y[2] + p.w * y[3];
-    }
-    if (PER_CHANNEL == 4) {       // the four pieces of a channel sit in the four lanes of a quad (PIECES % 4 == 0)
-      partial += dpp_f32<0xB1>(0.0f, partial);                          // quad_perm:[1,0,3,2]
-      partial += dpp_f32<0x4E>(0.0f, partial);                          // quad_perm:[2,3,0,1]
-    }
-    if (q < total && k % PER_CHANNEL == 0)
-      out[(base + j) * 3 + k / PER_CHANNEL] = t_clamp(partial + 0.5f, 0.0f, 1.0f);
-  }
-}
-
 template <typename T, int DEG>
 __global__ void __launch_bounds__(256)
 sh_bwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
@@ -193,7 +137,7 @@ sh_bwd_params_kernel(const T* __restrict__ positions, const int64_t* __restrict_
   __builtin_amdgcn_wave_barrier();   // LDS traffic stays inside the wave: no block barrier needed
 
   const int row = f * D;
-  if (UNIQUE && D % 4 == 0 && f == 3 && sizeof(T) == 4 && (reinterpret_cast<uintptr_t>(g_params) & 15) == 0) {
+  if (UNIQUE && D % 4 == 0 && f == 3 && sizeof(T) == 4) {
     // RGB, degree 1 / 3, float: the wave's count x 3 x D gradient values leave as 128-bit stores, four consecutive
     // coefficients of one (gaussian, channel) per lane — 1 KB per store instruction when the rows are adjacent
     // (every gaussian visible), 16-byte pieces of the right rows otherwise.  The row-at-a-time loop below issues
@@ -223,11 +167,6 @@ template <typename T>
 static int launch_sh_fwd(const void* params, const void* positions, const int64_t* indexes,
                          const void* cam, int64_t v, int f, int degree, void* out, hipStream_t s) {
   const dim3 block(256), grid((unsigned)div_up(v, 256));
-  if (sizeof(T) == 4 && f == 3 && (degree == 1 || degree == 3) && (reinterpret_cast<uintptr_t>(params) & 15) == 0) {
-    if (degree == 1) sh_fwd_rgb_kernel<1><<<grid, block, 0, s>>>((const float*)params, (const float*)positions, indexes, (const float*)cam, v, (float*)out);
-    else sh_fwd_rgb_kernel<3><<<grid, block, 0, s>>>((const float*)params, (const float*)positions, indexes, (const float*)cam, v, (float*)out);
-    return 0;
-  }
 #define MS_SH_FWD(DEG) \
   sh_fwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, indexes, (const T*)cam, v, f, (T*)out)
   switch (degree) {
