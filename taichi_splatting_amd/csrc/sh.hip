@@ -137,7 +137,7 @@ sh_bwd_params_kernel(const T* __restrict__ positions, const int64_t* __restrict_
   __builtin_amdgcn_wave_barrier();   // LDS traffic stays inside the wave: no block barrier needed
 
   const int row = f * D;
-  if (UNIQUE && D % 4 == 0 && f == 3 && sizeof(T) == 4) {
+  if (UNIQUE && D % 4 == 0 && f == 3 && sizeof(T) == 4 && (reinterpret_cast<uintptr_t>(g_params) & 15) == 0) {
     // RGB, degree 1 / 3, float: the wave's count x 3 x D gradient values leave as 128-bit stores, four consecutive
     // coefficients of one (gaussian, channel) per lane — 1 KB per store instruction when the rows are adjacent
     // (every gaussian visible), 16-byte pieces of the right rows otherwise.  The row-at-a-time loop below issues
