@@ -134,18 +134,26 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                        const float* __restrict__ image, const float* __restrict__ grad_image,
                        FastParams rp, float* __restrict__ moments) {
   constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
-  constexpr int BATCH = TS == 8 ? 128 : 256;     // splats staged per batch, shared by the tile's waves (uint8 indices)
-  constexpr int CAP = TS == 32 ? 96 : (HEUR && TS == 16) ? 104 : 128;   // heuristics: 11 accumulators per row, keep four workgroups per CU   // patch hits a wave takes on per pass (>= 64: a pass always advances)
+  // Splats staged per batch (shared by the tile's waves).  A tile's list is cut into EQUAL batches of about
+  // BATCH_TARGET (see the batch loop): with fixed 256-splat batches config D's ~779 splats per tile end in an
+  // 11-splat batch whose chunks run all 16 pixel steps for a couple of lanes — a quarter of all chunks.
+  constexpr int BATCH = TS == 8 ? 128 : (TS == 16 && !HEUR) ? 320 : 256;
+  constexpr int BATCH_TARGET = TS == 8 ? 112 : 256;
+  // patch hits a wave takes on per pass (>= 64: a pass always advances); sized with the records so that four
+  // workgroups fit a CU at tile 16 (11 accumulators per row with heuristics)
+  constexpr int CAP = TS == 32 ? 96 : TS == 16 ? (HEUR ? 104 : 112) : 128;
   constexpr int NACC = HEUR ? 11 : 9;
-  constexpr bool PIPELINED = THREADS >= BATCH;   // one staged splat per thread, gathered one batch ahead
-  // tile 16: 12 KB records + 1 KB ids + 4 x (4.5 KB accumulators + 0.6 KB lists + 1.25 KB pixels) = 38.5 KB: four
+  constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and 256 + t)
+  constexpr int SLOTS_B = PIPELINED ? BATCH - 256 : 0;     // second slot of the first SLOTS_B threads
+  static_assert(SLOTS_B >= 0 && SLOTS_B <= 64, "second staging slot: first wave only");
+  // tile 16: 15 KB records + 1.25 KB ids + 4 x (3.9 KB accumulators + 0.7 KB lists + 1.25 KB pixels) = 39.6 KB: four
   // workgroups per CU
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];
   // PER-WAVE gradient accumulators, one row per splat of the wave's patch list: plain read-add-write, no LDS
   // atomics (ds_add_f32 costs ~160 LDS cycles per instruction on gfx950, tools/ubench_scan.hip)
   __shared__ float s_acc[WAVES][CAP][NACC];
-  __shared__ uint8_t s_plist[WAVES][CAP];        // patch-list position -> staged index
+  __shared__ uint16_t s_plist[WAVES][CAP];       // patch-list position -> staged index
   __shared__ uint8_t s_list[WAVES][4][CAP];      // per sub-patch: patch-list positions of its hits, depth ordered
   // per-pixel data, read by ALL lanes of the wave at the pixel's step (same address: LDS broadcast; v_readlane
   // from state registers costs ~12-16 cycles per value on gfx950, tools/ubench_scan.hip):
@@ -182,15 +190,28 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
   const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
 
-  Raw raw;
-  int next_id = 0;
+  // equal batches: as many as it takes to stay near BATCH_TARGET (rounded to nearest), never above BATCH
+  const int total = end - start;
+  int num_batches = (total + BATCH_TARGET / 2) / BATCH_TARGET;
+  if (num_batches < 1) num_batches = 1;
+  int bsz = (total + num_batches - 1) / num_batches;
+  if (bsz > BATCH) { num_batches = (total + BATCH - 1) / BATCH; bsz = (total + num_batches - 1) / num_batches; }
+
+  // two-deep gather pipeline per staging slot: `raw` = splat data of the batch about to be staged, `next_id` =
+  // point index of the batch after it
+  Raw raw, raw_b;
+  int next_id = 0, next_id_b = 0;
   if (PIPELINED) {
-    if (t < BATCH && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
-    if (t < BATCH && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
+    if (t < bsz && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
+    if (t < bsz && start + bsz + t < end) next_id = o2p[start + bsz + t];
+    if (t < SLOTS_B) {
+      if (256 + t < bsz && start + 256 + t < end) raw_b = load_raw(points, feats, o2p[start + 256 + t]);
+      if (256 + t < bsz && start + bsz + 256 + t < end) next_id_b = o2p[start + bsz + 256 + t];
+    }
   }
 
-  for (int begin = start; begin < end; begin += BATCH) {
-    const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
+  for (int begin = start; begin < end; begin += bsz) {
+    const int count = (end - begin) < bsz ? (end - begin) : bsz;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
     wave_lds_fence();
@@ -201,8 +222,17 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         write_scan_record(raw, rp.alpha_threshold, &s_rec[t * 3]);
         s_id[t] = raw.id;
       }
-      if (t < BATCH && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
-      if (t < BATCH && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
+      if (t < bsz && begin + bsz + t < end) raw = load_raw(points, feats, next_id);
+      if (t < bsz && begin + 2 * bsz + t < end) next_id = o2p[begin + 2 * bsz + t];
+      if (t < SLOTS_B) {
+        const int sb = 256 + t;
+        if (sb < count) {
+          write_scan_record(raw_b, rp.alpha_threshold, &s_rec[sb * 3]);
+          s_id[sb] = raw_b.id;
+        }
+        if (sb < bsz && begin + bsz + sb < end) raw_b = load_raw(points, feats, next_id_b);
+        if (sb < bsz && begin + 2 * bsz + sb < end) next_id_b = o2p[begin + 2 * bsz + sb];
+      }
     } else {
       for (int s = t; s < count; s += THREADS) {
         const Raw r = load_raw(points, feats, o2p[begin + s]);
@@ -232,7 +262,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         const int nhit = __builtin_popcountll(m);
         if (pcount + nhit > CAP) break;          // next pass (nhit <= 64 <= CAP: an empty list always takes the group)
         const int ppos = pcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (hit) s_plist[wave][ppos] = (uint8_t)j;
+        if (hit) s_plist[wave][ppos] = (uint16_t)j;
         pcount += nhit;
         r += 64;
       }
