@@ -74,6 +74,26 @@ __device__ __forceinline__ float wave_scan_mul(float v) { MS_SCAN_ASM("v_mul_f32
 __device__ __forceinline__ float wave_scan_add(float v) { MS_SCAN_ASM("v_add_f32_dpp"); return v; }
 #undef MS_SCAN_ASM
 
+// The same scan on TWO independent registers, the two dependency chains interleaved: the kernel is bound by the
+// latency of these chains, not by issue slots, and one chain's instruction fills the other's DPP wait states
+// (a DPP read needs two wait states after the write of its source: the other chain's instruction + s_nop 0).
+#define MS_SCAN2_STEP(OP, CTRL)                                                                  \
+  OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+#define MS_SCAN2_ASM(OP)                                                                          \
+  asm("s_nop 1\n\t"                                                                               \
+      MS_SCAN2_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                                   \
+      MS_SCAN2_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                   \
+      MS_SCAN2_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                   \
+      MS_SCAN2_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")                                   \
+      MS_SCAN2_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                \
+      OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                               \
+      OP " %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf"                                    \
+      : "+v"(a), "+v"(b))
+__device__ __forceinline__ void wave_scan_mul2(float& a, float& b) { MS_SCAN2_ASM("v_mul_f32_dpp"); }
+__device__ __forceinline__ void wave_scan_add2(float& a, float& b) { MS_SCAN2_ASM("v_add_f32_dpp"); }
+#undef MS_SCAN2_ASM
+#undef MS_SCAN2_STEP
+
 // Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows, the pixel state written by
 // the last lane).  LDS operations of a wave execute in order, but the COMPILER reasons per thread: without a
 // fence it may keep a value this thread loaded earlier instead of re-reading what another lane stored (observed:
@@ -330,61 +350,85 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           int steps_run = 0, lanes_contrib = 0;
 #endif
 
-          // pixel data of the step after the current one is requested before the current step is evaluated
-          float4 pg = s_pix[wave][pbase];
-          float prg = s_rg[wave][pbase];
+          // The 16 pixels are visited in PAIRS (x, x + 1 of one pixel row): the two pixels are independent, so each
+          // pair runs two dependency chains side by side.  The data of the next pair is requested before the
+          // current pair is evaluated.
+          float4 pg[2] = {s_pix[wave][pbase], s_pix[wave][pbase + 1]};
+          float prg[2] = {s_rg[wave][pbase], s_rg[wave][pbase + 1]};
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
+          for (int i = 0; i < 16; i += 2) {
             const int p = pbase + i;
-            const float4 cur = pg;
-            const float RGin = prg;
-            if (i < 15) { pg = s_pix[wave][p + 1]; prg = s_rg[wave][p + 1]; }
-            const float Tin = cur.w;
-            if (__ballot(__float_as_uint(Tin) > oms_bits) != 0) {   // wave-uniform: saturated / out-of-image pixels are skipped
-              const float cx = (float)(i & 3);
-              const float X = (i & 3) == 0 ? Xr[i >> 2] : __builtin_fmaf(A, cx, Xr[i >> 2]);
-              const float Y = (i & 3) == 0 ? Yr[i >> 2] : __builtin_fmaf(C, cx, Yr[i >> 2]);
-              const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X, X, __builtin_fmaf(Y, Y, nl2a)));
+            const float4 cur[2] = {pg[0], pg[1]};
+            const float RGin[2] = {prg[0], prg[1]};
+            if (i < 14) {
+              pg[0] = s_pix[wave][p + 2]; pg[1] = s_pix[wave][p + 3];
+              prg[0] = s_rg[wave][p + 2]; prg[1] = s_rg[wave][p + 3];
+            }
+            // wave-uniform: a pair of saturated / out-of-image pixels is skipped; if only one of the two is dead, its
+            // lanes all find T <= 1 - saturate_threshold below and contribute nothing
+            if (__ballot(__float_as_uint(cur[0].w) > oms_bits || __float_as_uint(cur[1].w) > oms_bits) == 0) continue;
+
+            float X[2], Y[2], a_gated[2], a[2], om[2], Tk[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int x = (i + u) & 3, y = i >> 2;
+              X[u] = x == 0 ? Xr[y] : __builtin_fmaf(A, (float)x, Xr[y]);
+              Y[u] = x == 0 ? Yr[y] : __builtin_fmaf(C, (float)x, Yr[y]);
+              const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X[u], X[u], __builtin_fmaf(Y[u], Y[u], nl2a)));
               // blend gate (forward.py:99-101): lanes below the threshold carry alpha = 0 from here on
-              const float a_gated = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
-              float a = min_f32_uniform(a_gated, rp.clamp_max_alpha);
-              const float om = 1.0f - a;
-              // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- Tin)
-              const float Tk = wave_scan_mul(dpp_f32<0x138>(Tin, om));              // wave_shr:1
-              // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
-              // The pixel can cross that line inside at most one chunk of its life: wave-uniform slow path.
-              float a_st = a_gated;                                                // straight-through alpha (below)
-              if (__ballot(!(Tk > oms)) != 0) {
-                asm volatile("; saturation inside the chunk" ::: "memory");        // keep this a branch, not two selects per value
-                const bool live = Tk > oms;
-                a = live ? a : 0.0f;
-                a_st = live ? a_gated : 0.0f;
+              a_gated[u] = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
+              a[u] = min_f32_uniform(a_gated[u], rp.clamp_max_alpha);
+              om[u] = 1.0f - a[u];
+              // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)
+              Tk[u] = dpp_f32<0x138>(cur[u].w, om[u]);                              // wave_shr:1
+            }
+            wave_scan_mul2(Tk[0], Tk[1]);
+            // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
+            // A pixel crosses that line inside at most one chunk of its life: wave-uniform slow path.
+            float a_st[2] = {a_gated[0], a_gated[1]};                               // straight-through alpha (below)
+            if (__ballot(!(Tk[0] > oms) || !(Tk[1] > oms)) != 0) {
+              asm volatile("; saturation inside the chunk" ::: "memory");          // keep this a branch, not selects
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const bool live = Tk[u] > oms;
+                a[u] = live ? a[u] : 0.0f;
+                a_st[u] = live ? a_gated[u] : 0.0f;
               }
-              const float w = a * Tk;
-              const float g0 = cur.x, g1 = cur.y, g2 = cur.z;
-              const float fG = __builtin_fmaf(f2, g2, __builtin_fmaf(f1, g1, f0 * g0));
+            }
+            float w[2], fG[2], S[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              w[u] = a[u] * Tk[u];
+              fG[u] = __builtin_fmaf(f2, cur[u].z, __builtin_fmaf(f1, cur[u].y, f0 * cur[u].x));
+              S[u] = w[u] * fG[u];
+            }
+            wave_scan_add2(S[0], S[1]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
               // <R, G> after this splat: R -= f w  (backward.py:171-174)
-              const float RGk = RGin - wave_scan_add(w * fG);
+              const float RGk = RGin[u] - S[u];
               // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
-              const float ag = __builtin_fmaf(Tk, fG, -(RGk * __builtin_amdgcn_rcpf(om)));
+              const float ag = __builtin_fmaf(Tk[u], fG[u], -(RGk * __builtin_amdgcn_rcpf(om[u])));
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
-              const float q_ = ag * a_st;
-              const float qX = q_ * X, qY = q_ * Y;
+              const float q_ = ag * a_st[u];
+              const float qX = q_ * X[u], qY = q_ * Y[u];
               m0 += q_; m1 += qX; m2 += qY;
-              m3 = __builtin_fmaf(qX, X, m3); m4 = __builtin_fmaf(qX, Y, m4); m5 = __builtin_fmaf(qY, Y, m5);
-              a0 = __builtin_fmaf(w, g0, a0); a1 = __builtin_fmaf(w, g1, a1); a2 = __builtin_fmaf(w, g2, a2);
+              m3 = __builtin_fmaf(qX, X[u], m3); m4 = __builtin_fmaf(qX, Y[u], m4); m5 = __builtin_fmaf(qY, Y[u], m5);
+              a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
               if (HEUR) {                                           // backward.py:190-194
-                const float agm = a_st != 0.0f ? ag : 0.0f;
+                const float agm = a_st[u] != 0.0f ? ag : 0.0f;
                 h0 = __builtin_fmaf(agm, agm, h0);
                 h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
               }
               // the last lane holds the pixel's state after the whole chunk
-              if (last_lane) { s_pix[wave][p].w = Tk * om; s_rg[wave][p] = RGk; }
+              if (last_lane) { s_pix[wave][p + u].w = Tk[u] * om[u]; s_rg[wave][p + u] = RGk; }
 #if MS_SCAN_STATS
-              ++steps_run;
-              lanes_contrib += __builtin_popcountll(__ballot(w != 0.0f));
+              lanes_contrib += __builtin_popcountll(__ballot(w[u] != 0.0f));
 #endif
             }
+#if MS_SCAN_STATS
+            steps_run += 2;
+#endif
           }
 #if MS_SCAN_STATS
           if (lane == 0) {
