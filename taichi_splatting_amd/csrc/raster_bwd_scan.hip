@@ -94,6 +94,18 @@ __device__ __forceinline__ void wave_scan_add2(float& a, float& b) { MS_SCAN2_AS
 #undef MS_SCAN2_ASM
 #undef MS_SCAN2_STEP
 
+// Pixels per step.  Measured on config D (MI355X): 1 -> 1.65 ms, 2 -> 1.52 ms, 4 (one row of the sub-patch, no
+// wait states at all) -> 1.80 ms: the fourfold live state costs 154 VGPRs and a wave per SIMD.
+#define MS_SCAN_GROUP 2
+template <int U> __device__ __forceinline__ void wave_scan_mul_n(float (&v)[U]) {
+  static_assert(U == 2, "two interleaved chains");
+  wave_scan_mul2(v[0], v[1]);
+}
+template <int U> __device__ __forceinline__ void wave_scan_add_n(float (&v)[U]) {
+  static_assert(U == 2, "two interleaved chains");
+  wave_scan_add2(v[0], v[1]);
+}
+
 // Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows, the pixel state written by
 // the last lane).  LDS operations of a wave execute in order, but the COMPILER reasons per thread: without a
 // fence it may keep a value this thread loaded earlier instead of re-reading what another lane stored (observed:
@@ -353,24 +365,30 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           // The 16 pixels are visited in PAIRS (x, x + 1 of one pixel row): the two pixels are independent, so each
           // pair runs two dependency chains side by side.  The data of the next pair is requested before the
           // current pair is evaluated.
-          float4 pg[2] = {s_pix[wave][pbase], s_pix[wave][pbase + 1]};
-          float prg[2] = {s_rg[wave][pbase], s_rg[wave][pbase + 1]};
+          constexpr int U = MS_SCAN_GROUP;
+          float4 pg[U];
+          float prg[U];
 #pragma unroll
-          for (int i = 0; i < 16; i += 2) {
+          for (int u = 0; u < U; ++u) { pg[u] = s_pix[wave][pbase + u]; prg[u] = s_rg[wave][pbase + u]; }
+#pragma unroll
+          for (int i = 0; i < 16; i += U) {
             const int p = pbase + i;
-            const float4 cur[2] = {pg[0], pg[1]};
-            const float RGin[2] = {prg[0], prg[1]};
-            if (i < 14) {
-              pg[0] = s_pix[wave][p + 2]; pg[1] = s_pix[wave][p + 3];
-              prg[0] = s_rg[wave][p + 2]; prg[1] = s_rg[wave][p + 3];
-            }
-            // wave-uniform: a pair of saturated / out-of-image pixels is skipped; if only one of the two is dead, its
-            // lanes all find T <= 1 - saturate_threshold below and contribute nothing
-            if (__ballot(__float_as_uint(cur[0].w) > oms_bits || __float_as_uint(cur[1].w) > oms_bits) == 0) continue;
-
-            float X[2], Y[2], a_gated[2], a[2], om[2], Tk[2];
+            float4 cur[U];
+            float RGin[U];
+            bool any_alive = false;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
+              cur[u] = pg[u]; RGin[u] = prg[u];
+              any_alive |= __float_as_uint(cur[u].w) > oms_bits;
+              if (i + U < 16) { pg[u] = s_pix[wave][p + U + u]; prg[u] = s_rg[wave][p + U + u]; }
+            }
+            // wave-uniform: a group of saturated / out-of-image pixels is skipped; if only some of them are dead, their
+            // lanes all find T <= 1 - saturate_threshold below and contribute nothing
+            if (__ballot(any_alive) == 0) continue;
+
+            float X[U], Y[U], a_gated[U], a[U], om[U], Tk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
               const int x = (i + u) & 3, y = i >> 2;
               X[u] = x == 0 ? Xr[y] : __builtin_fmaf(A, (float)x, Xr[y]);
               Y[u] = x == 0 ? Yr[y] : __builtin_fmaf(C, (float)x, Yr[y]);
@@ -382,29 +400,32 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)
               Tk[u] = dpp_f32<0x138>(cur[u].w, om[u]);                              // wave_shr:1
             }
-            wave_scan_mul2(Tk[0], Tk[1]);
+            wave_scan_mul_n<U>(Tk);
             // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
             // A pixel crosses that line inside at most one chunk of its life: wave-uniform slow path.
-            float a_st[2] = {a_gated[0], a_gated[1]};                               // straight-through alpha (below)
-            if (__ballot(!(Tk[0] > oms) || !(Tk[1] > oms)) != 0) {
+            float a_st[U];                                                          // straight-through alpha (below)
+            bool any_sat = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a_st[u] = a_gated[u]; any_sat |= !(Tk[u] > oms); }
+            if (__ballot(any_sat) != 0) {
               asm volatile("; saturation inside the chunk" ::: "memory");          // keep this a branch, not selects
 #pragma unroll
-              for (int u = 0; u < 2; ++u) {
+              for (int u = 0; u < U; ++u) {
                 const bool live = Tk[u] > oms;
                 a[u] = live ? a[u] : 0.0f;
                 a_st[u] = live ? a_gated[u] : 0.0f;
               }
             }
-            float w[2], fG[2], S[2];
+            float w[U], fG[U], S[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
               w[u] = a[u] * Tk[u];
               fG[u] = __builtin_fmaf(f2, cur[u].z, __builtin_fmaf(f1, cur[u].y, f0 * cur[u].x));
               S[u] = w[u] * fG[u];
             }
-            wave_scan_add2(S[0], S[1]);
+            wave_scan_add_n<U>(S);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
               // <R, G> after this splat: R -= f w  (backward.py:171-174)
               const float RGk = RGin[u] - S[u];
               // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
@@ -427,7 +448,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #endif
             }
 #if MS_SCAN_STATS
-            steps_run += 2;
+            steps_run += U;
 #endif
           }
 #if MS_SCAN_STATS
