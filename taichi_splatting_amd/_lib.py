@@ -17,7 +17,7 @@ import torch
 
 PACKAGE_DIR = Path(__file__).resolve().parent
 CSRC_DIR = PACKAGE_DIR / 'csrc'
-LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB', PACKAGE_DIR / 'libmi355_splat.so'))   # env override: profiling builds
+LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB') or PACKAGE_DIR / 'libmi355_splat.so')   # env override: profiling builds
 
 MS_F32, MS_F64 = 0, 1
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h

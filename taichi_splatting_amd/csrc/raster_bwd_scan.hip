@@ -424,10 +424,19 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               S[u] = w[u] * fG[u];
             }
             wave_scan_add_n<U>(S);
+            // <R, G> after this splat: R -= f w  (backward.py:171-174)
+            float RGout[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) RGout[u] = RGin[u] - S[u];
+            // the last lane holds the state of both pixels after the whole chunk: one masked block, three LDS writes
+            if (last_lane) {
+              s_pix[wave][p].w = Tk[0] * om[0];
+              s_pix[wave][p + 1].w = Tk[1] * om[1];
+              *reinterpret_cast<float2*>(&s_rg[wave][p]) = make_float2(RGout[0], RGout[1]);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-              // <R, G> after this splat: R -= f w  (backward.py:171-174)
-              const float RGk = RGin[u] - S[u];
+              const float RGk = RGout[u];
               // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
               const float ag = __builtin_fmaf(Tk[u], fG[u], -(RGk * __builtin_amdgcn_rcpf(om[u])));
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
@@ -441,8 +450,6 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                 h0 = __builtin_fmaf(agm, agm, h0);
                 h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
               }
-              // the last lane holds the pixel's state after the whole chunk
-              if (last_lane) { s_pix[wave][p + u].w = Tk[u] * om[u]; s_rg[wave][p + u] = RGk; }
 #if MS_SCAN_STATS
               lanes_contrib += __builtin_popcountll(__ballot(w[u] != 0.0f));
 #endif

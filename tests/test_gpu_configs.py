@@ -257,7 +257,7 @@ def test_config_c_full_size():
     assert rel.flatten()[:8_000_000].quantile(0.999) < 2e-3 and (got - want).abs().max() < 2e-2 * scale
 
   r, grads = full_frame(g, cam, cfg)
-  assert r.image.shape == (1080, 1920, 3) and float(r.image.min()) >= 0
+  assert r.image.shape == (1080, 1920, 3) and float(r.image.detach().min()) >= 0
   strips_compose(g, cam, cfg, [0, 17, 34, 51, 68], r.image.detach(), grads)
 
 
