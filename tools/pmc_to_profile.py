@@ -2,13 +2,19 @@
 """Condense the rocprofv3 PMC passes of tools/pmc_collect.sh (summary.json) into the committed counter file that
 bench.py reads for `roofline.traffic` and `roofline.compute`:
 
-    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K > profiles/r02_raster_bwd_counters.json
+    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K [bwd.s fwd.s] > profiles/r02_raster_bwd_counters.json
+
+(bwd.s / fwd.s: hipcc -S output of raster_bwd_scan.hip / raster_fast.hip for the static instruction mix, tools/valu_mix.py)
 
 Derivations (MI355X_MICROARCH.md, "rocprofv3 PMC slots" / "HBM"):
   * FETCH_SIZE / WRITE_SIZE are reported in KB (x 1024 = bytes per launch); FETCH_SIZE under-reports wide coalesced
     streams by 2x on gfx950 — these kernels gather 4..16 B words, so the raw value is kept and the x2 value given
     as an upper bound;
-  * SQ_ACTIVE_INST_VALU counts quad-cycles (x4 = SIMD cycles a VALU instruction occupies its SIMD);
+  * SQ_ACTIVE_INST_VALU comes out at 1.04-1.06 per VALU instruction on both kernels whatever their mix, and x4 it
+    exceeds the wall clock on the forward kernel: it counts issue events, not the cycles an instruction occupies its
+    SIMD, so it is NOT used for a busy figure (it was in the first version of this file).  The busy estimate prices
+    the counted instructions with the per-class issue costs measured by tools/ubench_valu.hip / ubench_scan.hip and
+    the kernel's static instruction mix (tools/valu_mix.py) against the cycles of the same PMC run;
   * GRBM_GUI_ACTIVE is summed over the 8 XCDs: clock = GRBM_GUI_ACTIVE / 8 / duration;
   * VALU issue peak = 1024 SIMDs x clock / 2 cycles: a wave64 FP32 FMA / MUL issues in 2 cycles (the chip's
     157 TFLOP/s vector FP32 figure); DPP, select, compare, min/max and integer VALU instructions take 4, so a
@@ -18,6 +24,7 @@ import json
 import sys
 
 summary, n, size, tile, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+asm = sys.argv[6:8] if len(sys.argv) >= 8 else None
 d = json.load(open(summary))
 
 
@@ -28,7 +35,7 @@ def kernel(prefix):
   raise SystemExit(f"no kernel matching {prefix} in {summary}")
 
 
-def condense(prefix, algorithmic_bytes):
+def condense(prefix, algorithmic_bytes, mix=None):
   name, c = kernel(prefix)
   dur = c['mean_duration_us_under_pmc'] * 1e-6
   clock = c['GRBM_GUI_ACTIVE'] / 8 / dur
@@ -47,8 +54,8 @@ def condense(prefix, algorithmic_bytes):
       "clock_ghz": round(clock / 1e9, 3),
       "valu_instr_per_s": round(valu_per_s / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave64 VALU instr/s",
       "frac": round(valu_per_s / peak, 3),
-      "valu_active_cycles_per_instr": round(4 * c['SQ_ACTIVE_INST_VALU'] / c['SQ_INSTS_VALU'], 2),
-      "valu_busy_frac_of_wall": round(4 * c['SQ_ACTIVE_INST_VALU'] / 1024 / (clock * dur), 3),
+      "static_mix": mix,
+      "valu_busy_model": round(c['SQ_INSTS_VALU'] * mix["issue_cycles_per_instr"] / (1024 * c['GRBM_GUI_ACTIVE'] / 8), 3) if mix else None,
       "exec_lane_util": round(c['SQ_THREAD_CYCLES_VALU'] / (64 * c['SQ_ACTIVE_INST_VALU']), 3),
       "wave_cycles_split": {"issuing": round(c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES'], 3),
                             "issue_stalled": round(c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES'], 3),
@@ -62,15 +69,21 @@ def condense(prefix, algorithmic_bytes):
 
 p = size * size
 f = 3
-bwd = condense('raster_bwd_scan_kernel', (4 + 28 + 4 * f) * k + 8 * f * p + (28 + 4 * f) * k)
-fwd = condense('raster_fwd_f32x3_kernel', (4 + 28 + 4 * f) * k + 4 * (f + 1) * p)
+mix_bwd = mix_fwd = None
+if asm:
+  sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
+  from valu_mix import mix as valu_mix
+  mix_bwd = valu_mix(asm[0], f"_ZN2ms22raster_bwd_scan_kernelILi{tile}ELb0EEE")
+  mix_fwd = valu_mix(asm[1], f"_ZN2ms23raster_fwd_f32x3_kernelILi{tile}ELb0EEE")
+bwd = condense('raster_bwd_scan_kernel', (4 + 28 + 4 * f) * k + 8 * f * p + (28 + 4 * f) * k, mix_bwd)
+fwd = condense('raster_fwd_f32x3_kernel', (4 + 28 + 4 * f) * k + 4 * (f + 1) * p, mix_fwd)
 result = {
   "_comment": "rocprofv3 --pmc passes (tools/pmc_collect.sh: one counter group per run, kernel trace only) of "
               f"tools/prof_raster.py {n} {size} {tile} on one MI355X, condensed by tools/pmc_to_profile.py. Values per launch.",
   "workload": {"n": n, "width": size, "height": size, "tile": tile, "K": k},
   "traffic_bytes": bwd["traffic_bytes"],
-  "compute": {key: bwd["compute"][key] for key in ("valu_instr_per_s", "peak", "unit", "frac", "valu_active_cycles_per_instr",
-                                                     "valu_busy_frac_of_wall", "exec_lane_util", "clock_ghz", "valu_instr_per_launch")},
+  "compute": {key: bwd["compute"][key] for key in ("valu_instr_per_s", "peak", "unit", "frac", "static_mix", "valu_busy_model",
+                                                     "exec_lane_util", "clock_ghz", "valu_instr_per_launch")},
   "raster_bwd": bwd, "raster_fwd": fwd,
 }
 print(json.dumps(result, indent=1))
