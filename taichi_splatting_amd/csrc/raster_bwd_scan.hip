@@ -159,7 +159,11 @@ __device__ __forceinline__ bool scan_rect_hit(const float4 q0, const float4 q1, 
   return hit && (fabsf(p1) - e1 <= q2.w) && (fabsf(p2) - e2 <= q2.w);
 }
 
-template <int TS, bool HEUR>
+// SPLIT: the mapper's tile is (TS * SPLIT)^2 pixels and SPLIT^2 workgroups share its splat list, each taking one
+// TS x TS quarter.  Tile 32 runs as <16, HEUR, 2>: with one 1024-thread workgroup per tile a staged splat touches
+// few of the 16 patches and the per-wave lists stay short (4.0 ms on config D against 1.5 ms at tile 16); a
+// quarter stages the whole list (2.8x the splats that touch it) and then works exactly like a 16 x 16 tile.
+template <int TS, bool HEUR, int SPLIT = 1>
 __global__ void __launch_bounds__(TS * TS)
 raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
@@ -173,7 +177,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   constexpr int BATCH_TARGET = TS == 8 ? 112 : 256;
   // patch hits a wave takes on per pass (>= 64: a pass always advances); sized with the records so that four
   // workgroups fit a CU at tile 16 (11 accumulators per row with heuristics)
-  constexpr int CAP = TS == 32 ? 96 : TS == 16 ? (HEUR ? 104 : 112) : 128;
+  constexpr int CAP = TS == 16 ? (HEUR ? 104 : 112) : 128;
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and 256 + t)
   constexpr int SLOTS_B = PIPELINED ? BATCH - 256 : 0;     // second slot of the first SLOTS_B threads
@@ -193,11 +197,12 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   __shared__ float4 s_pix[WAVES][64];
   __shared__ float s_rg[WAVES][64];
 
-  const int tile_id = rp.tile_begin + blockIdx.x;
+  const int tile_id = rp.tile_begin + (int)(blockIdx.x / (SPLIT * SPLIT));
+  const int quarter = (int)(blockIdx.x % (SPLIT * SPLIT));
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int t = threadIdx.x, wave = t >> 6, lane = lane_id();
-  const int patch_x = tile_u * TS + (wave % WAVES_WIDE) * 8;
-  const int patch_y = tile_v * TS + (wave / WAVES_WIDE) * 8;
+  const int patch_x = (tile_u * SPLIT + quarter % SPLIT) * TS + (wave % WAVES_WIDE) * 8;
+  const int patch_y = (tile_v * SPLIT + quarter / SPLIT) * TS + (wave / WAVES_WIDE) * 8;
 
   // pixel state: lane p = 16 * sub + 4 * y + x holds pixel (x, y) of sub-patch `sub` (sub-patches 2 x 2)
   const int sub = lane >> 4;
@@ -577,16 +582,16 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
   rp.deterministic = deterministic != 0;
-  const dim3 grid((unsigned)((tile_row_end - tile_row_begin) * tiles_wide));
+  const unsigned tiles = (unsigned)((tile_row_end - tile_row_begin) * tiles_wide);
   hipStream_t s = (hipStream_t)stream;
-#define MS_GO(TS, HEUR) raster_bwd_scan_kernel<TS, HEUR><<<grid, dim3(TS * TS), 0, s>>>(                       \
+#define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT><<<dim3(tiles * SPLIT * SPLIT), dim3(TS * TS), 0, s>>>( \
       (const float*)points7, (const float*)features, tile_ranges, overlap_to_point, (const float*)image,      \
       (const float*)grad_image, rp, moments)
   const bool hf = cfg->compute_point_heuristic;
   switch (ts) {
-    case 8: if (hf) MS_GO(8, true); else MS_GO(8, false); break;
-    case 16: if (hf) MS_GO(16, true); else MS_GO(16, false); break;
-    default: if (hf) MS_GO(32, true); else MS_GO(32, false); break;
+    case 8: if (hf) MS_GO(8, true, 1); else MS_GO(8, false, 1); break;
+    case 16: if (hf) MS_GO(16, true, 1); else MS_GO(16, false, 1); break;
+    default: if (hf) MS_GO(16, true, 2); else MS_GO(16, false, 2); break;       // tile 32: four quarters per tile
   }
 #undef MS_GO
   MS_CHECK_LAUNCH();
