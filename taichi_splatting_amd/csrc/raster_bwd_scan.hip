@@ -10,13 +10,13 @@
 // Here the roles are transposed:
 //
 //   * one workgroup per tile, one wave per 8x8 pixel patch = four 4x4 SUB-PATCHES;
-//   * per staged batch (<= 256 splats, LDS) every wave tests the splats against each of its sub-patches (one
+//   * per staged batch (the tile's list in equal batches of <= 320 splats, LDS) every wave tests the splats against each of its sub-patches (one
 //     splat per lane, same conservative oriented-box test as the tile mapper, grid_query.py:30-43) and compacts
 //     the hits into per-sub-patch lists (ballot + mbcnt, order preserving => still depth sorted);
 //   * a sub-patch list is consumed in chunks of 64 hits with ONE SPLAT PER LANE.  The 16 pixels of the
-//     sub-patch are visited one after the other; the pixel (its coordinates, transmittance T, dL/dC and the
-//     colour still to come <R, G>) is wave-uniform: every lane reads it from the same LDS address (broadcast),
-//     one step ahead of its use.  The front-to-back recurrence over the 64 splats of the chunk is two DPP prefix scans:
+//     sub-patch are visited in pairs (two independent scan chains, interleaved); the pixel (its coordinates,
+//     transmittance T, dL/dC and the colour still to come <R, G>) is wave-uniform: every lane reads it from the
+//     same LDS address (broadcast), one step ahead of its use.  The front-to-back recurrence over the 64 splats of the chunk is two DPP prefix scans:
 //         T_k  = T_in * prod_{j<k} (1 - a_j)            (multiplicative, exclusive: wave_shr:1 + 6 v_mul_f32_dpp)
 //         S_k  = sum_{j<=k} w_j <f_j, G>                 (additive, inclusive: 6 v_add_f32_dpp)
 //     so each lane knows the T and <R, G> its splat sees at this pixel, evaluates d(alpha) and accumulates ITS
@@ -30,7 +30,7 @@
 //     ends with ONE 64-byte, line-aligned row of global float atomics per (8x8 patch, splat): 16 lanes commit the
 //     16 floats of moments[id] in one instruction.
 //
-// VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~56 instructions / (lanes filled) ~= 18 wave
+// VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~46 instructions / (lanes filled) ~= 16 wave
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
 #include "raster_common.h"
 
@@ -60,23 +60,13 @@ constexpr float FIXED_POINT_SCALE = 4294967296.0f;
 // (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row totals — six DPP instructions.  Lanes without a source
 // (and rows masked off) keep their value, which is the identity of the scan: exactly what v_*_dpp without
 // bound_ctrl does when it writes in place.  Written in assembly because LLVM's DPP combiner does not treat
-// 1.0f / 0.0f as identities of v_mul_f32 / v_add_f32 (it emits v_mov_b32 + v_mov_b32_dpp + v_mul_f32 per step);
-// "s_nop 1" = the two wait states a DPP read needs after the VALU write of its source.
-#define MS_SCAN_ASM(OP)                                                                           \
-  asm("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"                    \
-      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"                    \
-      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"                    \
-      "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"                    \
-      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
-      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"                      \
-      : "+v"(v))
-__device__ __forceinline__ float wave_scan_mul(float v) { MS_SCAN_ASM("v_mul_f32_dpp"); return v; }
-__device__ __forceinline__ float wave_scan_add(float v) { MS_SCAN_ASM("v_add_f32_dpp"); return v; }
-#undef MS_SCAN_ASM
-
-// The same scan on TWO independent registers, the two dependency chains interleaved: the kernel is bound by the
-// latency of these chains, not by issue slots, and one chain's instruction fills the other's DPP wait states
-// (a DPP read needs two wait states after the write of its source: the other chain's instruction + s_nop 0).
+// 1.0f / 0.0f as identities of v_mul_f32 / v_add_f32 (it emits v_mov_b32 + v_mov_b32_dpp + v_mul_f32 per step).
+//
+// The scan runs on TWO independent registers (two adjacent pixels) with the dependency chains interleaved: a DPP
+// read needs two wait states after the VALU write of its source, and the other chain's instruction + s_nop 0
+// provide them (a single chain needs s_nop 1 per level and leaves the SIMD idle for them).
+// Measured on config D (MI355X), pixels per step: 1 -> 1.65 ms, 2 -> 1.52 ms, 4 (one row of the sub-patch, no wait
+// states at all) -> 1.80 ms: the fourfold live state costs 154 VGPRs and a wave per SIMD.
 #define MS_SCAN2_STEP(OP, CTRL)                                                                  \
   OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
 #define MS_SCAN2_ASM(OP)                                                                          \
@@ -93,18 +83,6 @@ __device__ __forceinline__ void wave_scan_mul2(float& a, float& b) { MS_SCAN2_AS
 __device__ __forceinline__ void wave_scan_add2(float& a, float& b) { MS_SCAN2_ASM("v_add_f32_dpp"); }
 #undef MS_SCAN2_ASM
 #undef MS_SCAN2_STEP
-
-// Pixels per step.  Measured on config D (MI355X): 1 -> 1.65 ms, 2 -> 1.52 ms, 4 (one row of the sub-patch, no
-// wait states at all) -> 1.80 ms: the fourfold live state costs 154 VGPRs and a wave per SIMD.
-#define MS_SCAN_GROUP 2
-template <int U> __device__ __forceinline__ void wave_scan_mul_n(float (&v)[U]) {
-  static_assert(U == 2, "two interleaved chains");
-  wave_scan_mul2(v[0], v[1]);
-}
-template <int U> __device__ __forceinline__ void wave_scan_add_n(float (&v)[U]) {
-  static_assert(U == 2, "two interleaved chains");
-  wave_scan_add2(v[0], v[1]);
-}
 
 // Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows, the pixel state written by
 // the last lane).  LDS operations of a wave execute in order, but the COMPILER reasons per thread: without a
@@ -370,7 +348,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           // The 16 pixels are visited in PAIRS (x, x + 1 of one pixel row): the two pixels are independent, so each
           // pair runs two dependency chains side by side.  The data of the next pair is requested before the
           // current pair is evaluated.
-          constexpr int U = MS_SCAN_GROUP;
+          constexpr int U = 2;                     // pixels per step (see wave_scan_mul2)
           float4 pg[U];
           float prg[U];
 #pragma unroll
@@ -405,7 +383,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)
               Tk[u] = dpp_f32<0x138>(cur[u].w, om[u]);                              // wave_shr:1
             }
-            wave_scan_mul_n<U>(Tk);
+            wave_scan_mul2(Tk[0], Tk[1]);
             // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
             // A pixel crosses that line inside at most one chunk of its life: wave-uniform slow path.
             float a_st[U];                                                          // straight-through alpha (below)
@@ -428,7 +406,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               fG[u] = __builtin_fmaf(f2, cur[u].z, __builtin_fmaf(f1, cur[u].y, f0 * cur[u].x));
               S[u] = w[u] * fG[u];
             }
-            wave_scan_add_n<U>(S);
+            wave_scan_add2(S[0], S[1]);
             // <R, G> after this splat: R -= f w  (backward.py:171-174)
             float RGout[U];
 #pragma unroll
