@@ -175,8 +175,12 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   __shared__ float4 s_pix[WAVES][64];
   __shared__ float s_rg[WAVES][64];
 
-  const int tile_id = rp.tile_begin + (int)(blockIdx.x / (SPLIT * SPLIT));
-  const int quarter = (int)(blockIdx.x % (SPLIT * SPLIT));
+  unsigned quarter_u;
+  // the quarter workgroups of a tile run on one XCD (they stage the same list); tiles themselves in plain order
+  const int local_tile = xcd_tile<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, blockIdx.x, SPLIT * SPLIT, &quarter_u);
+  if (local_tile < 0) return;
+  const int tile_id = rp.tile_begin + local_tile;
+  const int quarter = (int)quarter_u;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int t = threadIdx.x, wave = t >> 6, lane = lane_id();
   const int patch_x = (tile_u * SPLIT + quarter % SPLIT) * TS + (wave % WAVES_WIDE) * 8;
@@ -539,16 +543,19 @@ raster_moments_finalize_kernel(const float* __restrict__ points, const float* __
 
 using namespace ms;
 
-extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
-                                     const int32_t* overlap_to_point, const void* image, const void* grad_image,
-                                     int image_w, int image_h, const ms_raster_config* cfg, float* moments,
-                                     int deterministic, int tile_row_begin, int tile_row_end, void* stream) {
-  MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments, "null pointer");
-  MS_CHECK_ARG(image_w > 0 && image_h > 0, "bad image size");
-  MS_CHECK_ARG(cfg->use_alpha_blending, "backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)");
-  if (cfg->antialias) { set_error("ms_raster_bwd_moments: antialiased pdf is served by ms_raster_bwd"); return MS_ERR_UNSUPPORTED; }
+static int launch_scan_backward(const float* points7, const float* features,
+                                const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
+                                const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
+                                float* moments, int deterministic, int tile_row_begin, int tile_row_end, hipStream_t s,
+                                const char* who) {
+  if (image_w <= 0 || image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
+  if (!cfg->use_alpha_blending) {
+    set_error("%s: backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)", who);
+    return MS_ERR_BAD_ARG;
+  }
+  if (cfg->antialias) { set_error("%s: antialiased pdf is served by ms_raster_bwd", who); return MS_ERR_UNSUPPORTED; }
   const int ts = cfg->tile_size;
-  if (ts != 8 && ts != 16 && ts != 32) { set_error("ms_raster_bwd_moments: tile_size must be 8, 16 or 32 (got %d)", ts); return MS_ERR_UNSUPPORTED; }
+  if (ts != 8 && ts != 16 && ts != 32) { set_error("%s: tile_size must be 8, 16 or 32 (got %d)", who, ts); return MS_ERR_UNSUPPORTED; }
   const int tiles_high = (image_h + ts - 1) / ts, tiles_wide = (image_w + ts - 1) / ts;
   if (tile_row_begin < 0) tile_row_begin = 0;
   if (tile_row_end > tiles_high) tile_row_end = tiles_high;
@@ -560,20 +567,32 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
   rp.deterministic = deterministic != 0;
-  const unsigned tiles = (unsigned)((tile_row_end - tile_row_begin) * tiles_wide);
-  hipStream_t s = (hipStream_t)stream;
-#define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT><<<dim3(tiles * SPLIT * SPLIT), dim3(TS * TS), 0, s>>>( \
-      (const float*)points7, (const float*)features, tile_ranges, overlap_to_point, (const float*)image,      \
-      (const float*)grad_image, rp, moments)
+  rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
+#define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT>                                           \
+      <<<dim3(xcd_grid<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, SPLIT * SPLIT)), dim3(TS * TS), 0, s>>>(              \
+          points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments)
+#define MS_GO_TILE(TS, SPLIT)                                                                                   \
+  do { if (hf) MS_GO(TS, true, SPLIT); else MS_GO(TS, false, SPLIT); } while (0)
   const bool hf = cfg->compute_point_heuristic;
   switch (ts) {
-    case 8: if (hf) MS_GO(8, true, 1); else MS_GO(8, false, 1); break;
-    case 16: if (hf) MS_GO(16, true, 1); else MS_GO(16, false, 1); break;
-    default: if (hf) MS_GO(16, true, 2); else MS_GO(16, false, 2); break;       // tile 32: four quarters per tile
+    case 8: MS_GO_TILE(8, 1); break;
+    case 16: MS_GO_TILE(16, 1); break;
+    default: MS_GO_TILE(16, 2); break;       // tile 32: four quarter workgroups per tile
   }
+#undef MS_GO_TILE
 #undef MS_GO
   MS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
+                                     const int32_t* overlap_to_point, const void* image, const void* grad_image,
+                                     int image_w, int image_h, const ms_raster_config* cfg, float* moments,
+                                     int deterministic, int tile_row_begin, int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments, "null pointer");
+  return launch_scan_backward((const float*)points7, (const float*)features, tile_ranges, overlap_to_point,
+                              (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
+                              deterministic, tile_row_begin, tile_row_end, (hipStream_t)stream, "ms_raster_bwd_moments");
 }
 
 #if MS_SCAN_STATS

@@ -10,7 +10,40 @@ struct FastParams {
   int width, height, tiles_wide, tile_begin;
   float clamp_max_alpha, alpha_threshold, one_minus_saturate;
   int deterministic;      // raster_bwd_scan.hip: order-independent (fixed-point integer) gradient commits
+  int num_tiles;          // tiles of this launch (xcd_tile)
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share splats (a gaussian
+// overlaps 2.1 tiles on config D; the four quarter workgroups of a 32 x 32 tile share ALL of them), so an XCD may
+// take runs of CHUNK consecutive tiles instead of every eighth tile: block b -> XCD b % 8, position b / 8 in that
+// XCD's sequence; `parts` consecutive positions belong to one tile (*part = which); run r of the XCD is tile run
+// r * 8 + xcd.  CHUNK = 0: plain order.  Measured on config D (tile 8 / 16 / 32, ms):
+//   forward   plain 0.73 / 0.667 / 0.78   CHUNK 2: 0.68 / 0.658 / 0.78   CHUNK 8: 0.65 / 0.651 / 0.78   CHUNK 32: 0.66 / 0.655 / 0.79
+//   backward  plain 1.69 / 1.525 / 3.09   CHUNK 2: 1.68 / 1.532 / 3.04   CHUNK 8: 1.70 / 1.564 / 3.05   CHUNK 32: 1.73 / 1.600 / 3.04
+//   (one contiguous eighth of the image per XCD: backward 1.64 at tile 16 — the eight bands are not equally heavy)
+// The forward (bound by VALU, LDS and the gathers together) gains from the shared L2 lines; the backward does not
+// (its gathers hide behind the blend phases, and tiles that share splats commit to the same moments rows).
+// Launch xcd_grid<CHUNK>() blocks; xcd_tile() returns -1 for the padding blocks.
+constexpr unsigned NUM_XCD = 8;
+template <unsigned CHUNK>
+__device__ __forceinline__ int xcd_tile(int num_tiles, unsigned block, unsigned parts, unsigned* part) {
+  if constexpr (CHUNK == 0) {
+    *part = block % parts;
+    return block / parts < (unsigned)num_tiles ? (int)(block / parts) : -1;
+  } else {
+    const unsigned xcd = block % NUM_XCD, pos = block / NUM_XCD;
+    const unsigned tpos = pos / parts, run = tpos / CHUNK, within = tpos % CHUNK;
+    const unsigned tile = (run * NUM_XCD + xcd) * CHUNK + within;
+    *part = pos % parts;
+    return tile < (unsigned)num_tiles ? (int)tile : -1;
+  }
+}
+template <unsigned CHUNK>
+static inline unsigned xcd_grid(int num_tiles, unsigned parts) {
+  if (CHUNK == 0) return (unsigned)num_tiles * parts;
+  const unsigned span = NUM_XCD * CHUNK;
+  return ((unsigned)num_tiles + span - 1) / span * span * parts;
+}
 
 // raw per-splat data in flight between the gather and the LDS write (one batch ahead)
 struct Raw {

@@ -32,6 +32,8 @@ namespace ms {
 // (forward.py:126-131): one 6-step DPP sum per (patch, splat) hit with a contribution, summed over the
 // tile's patches in LDS (single-lane ds_add_f32) and committed with ONE global atomic per (tile, splat) —
 // the pass is bound by the global atomic rate, so the count is what matters.
+constexpr unsigned FWD_XCD_CHUNK = 8;      // tiles per XCD run (xcd_tile, raster_common.h)
+
 template <int TS, bool VIS>
 __global__ void __launch_bounds__(TS * TS)
 raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
@@ -45,7 +47,10 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   __shared__ int32_t s_id[VIS ? BATCH : 1];
   __shared__ float s_vis[VIS ? BATCH : 1];
 
-  const int tile_id = rp.tile_begin + blockIdx.x;
+  unsigned part_;
+  const int local_tile = xcd_tile<FWD_XCD_CHUNK>(rp.num_tiles, blockIdx.x, 1, &part_);
+  if (local_tile < 0) return;
+  const int tile_id = rp.tile_begin + local_tile;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int patch_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8;
@@ -157,7 +162,10 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   constexpr int NOUT = HEUR ? 3 : 2;
   __shared__ uint32_t s_off[NOUT][BATCH];
 
-  const int tile_id = rp.tile_begin + blockIdx.x;
+  unsigned part_;
+  const int local_tile = xcd_tile<0>(rp.num_tiles, blockIdx.x, 1, &part_);
+  if (local_tile < 0) return;
+  const int tile_id = rp.tile_begin + local_tile;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int patch_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8;
@@ -296,7 +304,7 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 
 using namespace ms;
 
-static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, int row_begin) {
+static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, int row_begin, int num_tiles) {
   FastParams rp;
   rp.width = w; rp.height = h;
   rp.tiles_wide = (w + cfg->tile_size - 1) / cfg->tile_size;
@@ -305,6 +313,7 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
   rp.deterministic = 0;
+  rp.num_tiles = num_tiles;
   return rp;
 }
 
@@ -312,8 +321,8 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
                         int row_begin, int num_tiles, hipStream_t s) {
-  const FastParams rp = make_fast_params(w, h, cfg, row_begin);
-  const dim3 grid((unsigned)num_tiles);
+  const FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
+  const dim3 grid(xcd_grid<FWD_XCD_CHUNK>(rp.num_tiles, 1));
 #define MS_GO(TS)                                                                                               \
   do {                                                                                                          \
     if (visibility) raster_fwd_f32x3_kernel<TS, true><<<grid, dim3(TS * TS), 0, s>>>(                           \
@@ -333,8 +342,8 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
 bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s) {
-  const FastParams rp = make_fast_params(w, h, cfg, row_begin);
-  const dim3 grid((unsigned)num_tiles);
+  const FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
+  const dim3 grid(xcd_grid<0>(rp.num_tiles, 1));
   const bool hf = cfg->compute_point_heuristic && heur;
 #define MS_GO(TS, HEUR) raster_bwd_f32x3_kernel<TS, HEUR><<<grid, dim3(TS * TS), 0, s>>>(                   \
       (const float*)points, (const float*)feats, ranges, o2p, (const float*)image, (const float*)grad_image, \
