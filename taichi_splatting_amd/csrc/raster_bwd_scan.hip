@@ -46,7 +46,7 @@
 namespace ms {
 
 #if MS_SCAN_STATS
-__device__ unsigned long long g_scan_stats[8];
+__device__ unsigned long long g_scan_stats[10];
 #endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
@@ -229,12 +229,26 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     }
   }
 
+#if MS_SCAN_STATS
+  __shared__ int s_bsum, s_bmax;
+  if (t == 0) { s_bsum = 0; s_bmax = 0; }
+#define MS_FLUSH_BALANCE()                                                                                      \
+  if (t == 0) {                                                                                                 \
+    atomicAdd(&g_scan_stats[8], (unsigned long long)s_bsum);                                                    \
+    atomicAdd(&g_scan_stats[9], (unsigned long long)(s_bmax * WAVES));                                          \
+    s_bsum = 0; s_bmax = 0;                                                                                     \
+  }
+#endif
   for (int begin = start; begin < end; begin += bsz) {
     const int count = (end - begin) < bsz ? (end - begin) : bsz;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
     wave_lds_fence();
-    if (__syncthreads_and(__float_as_uint(s_pix[wave][lane].w) <= oms_bits)) break;
+    const bool tile_done = __syncthreads_and(__float_as_uint(s_pix[wave][lane].w) <= oms_bits);
+#if MS_SCAN_STATS
+    MS_FLUSH_BALANCE()
+#endif
+    if (tile_done) break;
 
     if (PIPELINED) {
       if (t < count) {
@@ -267,6 +281,11 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     continue;
 #endif
 
+#if MS_SCAN_STATS
+    // balance of the blend work between the waves of a workgroup: per batch, sum and WAVES x max of the chunks
+    // the waves ran (a batch ends at a barrier, so the slowest wave sets its length)
+    int batch_chunks = 0;
+#endif
     // From here to the next barrier the wave works alone: it walks the staged batch in passes of at most CAP
     // patch hits (one pass per batch unless most staged splats touch this 8x8 patch).
     int r = 0;
@@ -446,6 +465,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #endif
           }
 #if MS_SCAN_STATS
+          ++batch_chunks;
           if (lane == 0) {
             atomicAdd(&g_scan_stats[2], 1ull);                                           // chunks
             atomicAdd(&g_scan_stats[3], (unsigned long long)min(64, n - c0));             // filled lanes
@@ -483,7 +503,15 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       }
       wave_lds_fence();
     }
+#if MS_SCAN_STATS
+    if (lane == 0) { atomicAdd(&s_bsum, batch_chunks); atomicMax(&s_bmax, batch_chunks); }
+#endif
   }
+#if MS_SCAN_STATS
+  __syncthreads();
+  MS_FLUSH_BALANCE()
+#undef MS_FLUSH_BALANCE
+#endif
 }
 
 // Moments -> gradients of the packed 2D gaussian and its colour (one thread per point; plain stores).
@@ -596,9 +624,9 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
 }
 
 #if MS_SCAN_STATS
-extern "C" int ms_debug_scan_stats(unsigned long long* out8, int reset) {
-  if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_scan_stats), 8 * sizeof(unsigned long long));
-  if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
+extern "C" int ms_debug_scan_stats(unsigned long long* out10, int reset) {
+  if (out10) (void)hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_scan_stats), 10 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[10] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
   return 0;
 }
 #endif
