@@ -73,8 +73,8 @@ mix_bwd = mix_fwd = None
 if asm:
   sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent))
   from valu_mix import mix as valu_mix
-  mix_bwd = valu_mix(asm[0], f"_ZN2ms22raster_bwd_scan_kernelILi{tile}ELb0EEE")
-  mix_fwd = valu_mix(asm[1], f"_ZN2ms23raster_fwd_f32x3_kernelILi{tile}ELb0EEE")
+  mix_bwd = valu_mix(asm[0], f"_ZN2ms22raster_bwd_scan_kernelILi{tile}ELb0E")
+  mix_fwd = valu_mix(asm[1], f"_ZN2ms23raster_fwd_f32x3_kernelILi{tile}ELb0E")
 bwd = condense('raster_bwd_scan_kernel', (4 + 28 + 4 * f) * k + 8 * f * p + (28 + 4 * f) * k, mix_bwd)
 fwd = condense('raster_fwd_f32x3_kernel', (4 + 28 + 4 * f) * k + 4 * (f + 1) * p, mix_fwd)
 result = {
