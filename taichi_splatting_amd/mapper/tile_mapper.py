@@ -107,6 +107,9 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     _lib.check(lib.ms_exclusive_scan_i32(counts.data_ptr(), v, cum.data_ptr(), None, tmp.data_ptr(),
                                          ctypes.byref(nbytes), stream), "map_to_tiles")
     total = int(cum[v].item())
+    if total < 0:
+      raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
+                          "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
     if total == 0:
       return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
 
