@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Randomised cross-check of the two float RGB raster backward organisations (development tool): the splat-per-lane
+"""Randomised cross-check of the float RGB raster kernels (development tool): the float32 forward (+ visibility) against
+the float64 generic forward, and the two backward organisations against each other: the splat-per-lane
 scan kernel (ms_raster_bwd_moments + finalize, plain and deterministic) against the pixel-per-lane kernel
 (ms_raster_bwd) on random 2D scenes — image sizes that are not tile multiples, tiny and huge splats, alphas
 around the thresholds, empty and crowded tiles, strips of tile rows.  Both run in float32; they must agree to
@@ -10,6 +11,7 @@ float32 gate decision (see the comment at the criterion; --diag brings in the fl
 """
 import argparse
 import sys
+from dataclasses import replace
 from pathlib import Path
 
 import torch
@@ -55,6 +57,21 @@ def main():
       o2p, ranges = map_to_tiles(g2d, depth, (w, h), cfg)
       ranges2 = ranges.view(-1, 2)
       image = rasterize_with_tiles(g2d, feats, o2p, ranges2, (w, h), cfg).image
+      # forward: the float32 product kernel (+ visibility) against the float64 generic kernel on the same lists
+      cfg_vis = replace(cfg, compute_visibility=True, compute_point_heuristic=False)
+      out32 = rasterize_with_tiles(g2d, feats, o2p, ranges2, (w, h), cfg_vis)
+      out64 = rasterize_with_tiles(g2d.double(), feats.double(), o2p, ranges2, (w, h), cfg_vis)
+      px_off = int(((out32.image.double() - out64.image).abs().amax(-1) > 1e-4).sum())
+      px_allowed = max(8, int(2e-3 * w * h))
+      vis_scale = float(out64.visibility.abs().max())
+      vis_off = int(((out32.visibility.double() - out64.visibility).abs() > 1e-3 * max(vis_scale, 1e-30)).sum())
+      fwd_typical = float((out32.image.double() - out64.image).abs().median())
+      if not (torch.isfinite(out32.image).all() and px_off <= px_allowed and vis_off <= max(24, int(2e-3 * n)) and fwd_typical <= 1e-5
+              and torch.equal(out32.image, image)):
+        tag = (f"seed {seed} forward: tile {tile} {w}x{h} n={n} K={o2p.shape[0]} scale={scale:.2f} thr={cfg.alpha_threshold:.3f} "
+               f"pixels off={px_off} (allowed {px_allowed}) visibility off={vis_off} median={fwd_typical:.1e}")
+        failures.append(tag)
+        print("FAIL", tag, flush=True)
       grad_image = torch.rand(image.shape, generator=gen).to(dev) - 0.3
       th = (h + tile - 1) // tile
       row0 = ri(0, th - 1) if ri(0, 3) == 0 else 0            # sometimes a strip of tile rows
