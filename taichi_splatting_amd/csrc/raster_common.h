@@ -160,6 +160,22 @@ __device__ __forceinline__ float wave_reduce16(const float (&v)[16], bool b0, bo
   return __uint_as_float(p2[0]) + __uint_as_float(p2[1]);
 }
 
+// Four values per lane -> their wave totals: lanes with (lane & 15) >= 12 of EVERY row end with the total of
+// v[lane & 3].  Two quad stages as above (6 v_cndmask + 3 v_add_dpp), row_shr:4/8, then the rows and wave halves are
+// summed with v_permlane16_swap / v_permlane32_swap of the value with itself: 17 VALU instructions for four sums
+// (the forward's per-splat visibility: four hits share one reduction instead of 6 DPP adds each).
+__device__ __forceinline__ float wave_reduce4(const float (&v)[4], bool b0, bool b1) {
+  const float a = add_dpp<0xB1>(b0 ? v[1] : v[0], b0 ? v[0] : v[1]);          // quad_perm:[1,0,3,2]
+  const float b = add_dpp<0xB1>(b0 ? v[3] : v[2], b0 ? v[2] : v[3]);
+  float c = add_dpp<0x4E>(b1 ? b : a, b1 ? a : b);                            // quad_perm:[2,3,0,1]
+  c = add_dpp<0x114>(c, c);                                                   // row_shr:4
+  c = add_dpp<0x118>(c, c);                                                   // row_shr:8
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+  const float s = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
 // v_min_f32 without the canonicalising v_max hipcc puts in front of fminf (inputs are never sNaN here)
 __device__ __forceinline__ float min_f32(float a, float b) {
   float r;

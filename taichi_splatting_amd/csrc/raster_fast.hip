@@ -98,6 +98,38 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
       unsigned long long m = __ballot(hit);
       if (m == 0) continue;
+      if constexpr (VIS) {
+        // visibility = per-splat sum of the blend weights (forward.py:126-131): the hits are taken four at a time
+        // and ONE transposing reduction (wave_reduce4, 17 VALU) yields the four sums — 6 DPP adds + a ballot per hit
+        // before; lanes 60..63 add them to the tile's LDS row, the stager commits that row once per (tile, splat)
+        while (m != 0) {
+          float wq[4] = {0.f, 0.f, 0.f, 0.f};
+          int bq[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m != 0) {                                   // wave-uniform
+              const int b = __builtin_ctzll(m);
+              m &= m - 1;
+              bq[u] = b;
+              const float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1];
+              const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
+              const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
+              const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
+              const float a = min_f32(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
+              const float w = a > rp.alpha_threshold ? a * T : 0.0f;
+              T -= w;
+              c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
+              wq[u] = w;
+            }
+          }
+          const float total = wave_reduce4(wq, (lane & 1) != 0, (lane & 2) != 0);
+          if (lane >= 60 && total != 0.0f) {
+            const int k = lane & 3;
+            atomicAdd(&s_vis[r + (k == 0 ? bq[0] : k == 1 ? bq[1] : k == 2 ? bq[2] : bq[3])], total);
+          }
+        }
+        continue;
+      }
       int b = __builtin_ctzll(m);
       m &= m - 1;
       // the forward uses 40 of the record's 48 bytes: the third read is 64 bits (the LDS pipe is ~80 % busy here)
@@ -119,12 +151,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
         T -= w;
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
-        if (VIS) {
-          if (__ballot(w != 0.0f)) {
-            const float total = wave_sum_to_lane63(w);
-            if (lane == 63) atomicAdd(&s_vis[r + b], total);
-          }
-        }
 
         if (!more) break;
         b = nb; q0 = n0; q1 = n1; q2 = n2;

@@ -209,7 +209,7 @@ def strips_compose(g, cam, cfg, bounds, full_image, full_grads):
     r = render_gaussians(g, cam, cfg, use_sh=True, tile_rows=(b0, b1))
     y0, y1 = min(b0 * ts, h), min(b1 * ts, h)
     assert torch.equal(r.image[y0:y1], full_image[y0:y1])
-    assert float(r.image[:y0].abs().sum()) == 0 and float(r.image[y1:].abs().sum()) == 0
+    assert float(r.image.detach()[:y0].abs().sum()) == 0 and float(r.image.detach()[y1:].abs().sum()) == 0
     r.image.sum().backward()
   for k, want in zip(LEAVES, full_grads):
     got = getattr(g, k).grad
