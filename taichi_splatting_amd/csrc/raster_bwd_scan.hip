@@ -151,16 +151,20 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // Splats staged per batch (shared by the tile's waves).  A tile's list is cut into EQUAL batches of about
   // BATCH_TARGET (see the batch loop): with fixed 256-splat batches config D's ~779 splats per tile end in an
   // 11-splat batch whose chunks run all 16 pixel steps for a couple of lanes — a quarter of all chunks.
-  constexpr int BATCH = TS == 8 ? 128 : (TS == 16 && !HEUR) ? 320 : 256;
+  constexpr int BATCH = TS == 8 ? 128 : (TS == 16 && !HEUR) ? 268 : 256;
   constexpr int BATCH_TARGET = TS == 8 ? 112 : 256;
-  // patch hits a wave takes on per pass (>= 64: a pass always advances); sized with the records so that four
-  // workgroups fit a CU at tile 16 (11 accumulators per row with heuristics)
-  constexpr int CAP = TS == 16 ? (HEUR ? 104 : 112) : 128;
+  // Patch hits a wave takes on per pass (>= 64: a pass always advances) = rows of its accumulator.  A wave whose
+  // patch list overflows runs the rest of the batch as a second pass with nearly empty chunks, so at tile 16 the
+  // 40 KB a workgroup may use (four per CU) go to CAP first and to the staging batch second (config D, ms;
+  // a batch of ~260 splats puts ~100 on an 8x8 patch):
+  //   BATCH / CAP   320 / 112: 1.50    268 / 128: 1.43    256 / 132: 1.51    (3.27 / 3.04 / 3.04 at 4096^2)
+  //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
+  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : 128;
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and 256 + t)
   constexpr int SLOTS_B = PIPELINED ? BATCH - 256 : 0;     // second slot of the first SLOTS_B threads
   static_assert(SLOTS_B >= 0 && SLOTS_B <= 64, "second staging slot: first wave only");
-  // tile 16: 15 KB records + 1.25 KB ids + 4 x (3.9 KB accumulators + 0.7 KB lists + 1.25 KB pixels) = 39.6 KB: four
+  // tile 16: 12.6 KB records + 1 KB ids + 4 x (4.5 KB accumulators + 0.75 KB lists + 1.25 KB pixels) = 39.9 KB: four
   // workgroups per CU
   __shared__ float4 s_rec[BATCH * 3];
   __shared__ int32_t s_id[BATCH];

@@ -34,7 +34,7 @@ DETERMINISTIC_BACKWARD = os.environ.get('MS_DETERMINISTIC', '0') not in ('0', ''
 
 def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
   """Product path (float32 RGB, plain pdf, tile 8 / 16): the splat-per-lane scan kernel of csrc/raster_bwd_scan.hip
-  (config D: 1.52 + 0.14 ms at tile 16, 1.71 + 0.14 ms at tile 8).  At tile 32 the scan kernel runs four 16 x 16
+  (config D: 1.43 + 0.14 ms at tile 16, 1.65 + 0.14 ms at tile 8).  At tile 32 the scan kernel runs four 16 x 16
   quarter workgroups per tile, each staging the whole tile list (3.10 + 0.14 ms, half of it the fourfold staging);
   the pixel-per-lane kernel of raster_fast.hip takes 3.09 ms there and keeps that tile size — except in the
   deterministic mode, which only the scan kernel has.  ``MS_RASTER_BWD=patch`` forces the pixel-per-lane kernels
