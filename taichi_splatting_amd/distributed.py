@@ -71,19 +71,21 @@ def allreduce_boundary_grads(grad_points: torch.Tensor, grad_features: torch.Ten
   return buf[:n, :grad_points.shape[1]], buf[:n, grad_points.shape[1]:]
 
 
-def _tie_to_exchange(loss: torch.Tensor, g2: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
-  """Root for ``backward()`` that ALWAYS reaches the 2D boundary tensors, with zero extra gradient.
+def backward_through_exchange(loss: torch.Tensor, g2: torch.Tensor, f2: torch.Tensor, ran: Optional[dict] = None):
+  """``loss.backward()`` for a rank step whose gradient collective sits behind ``g2`` / ``f2`` in the graph.
 
-  The gradient collectives (all-reduce / reverse all-to-all) sit behind ``g2`` / ``f2`` in the graph, so every
-  rank must run them or the others hang.  A ``loss_fn`` may return a constant for an empty strip (more ranks than
-  tile rows, zero-weight rows of a balanced split): such a loss does not depend on the strip image.  Adding
-  ``0 * g2[:1].sum()`` makes the dependency unconditional; the value of the loss reported to the caller is the
-  untouched one."""
-  root = loss
-  for t in (g2, f2):
-    if t.requires_grad:
-      root = root + 0.0 * t[:1].sum().to(loss.dtype)
-  return root
+  Every rank must run that collective or the others hang, but a ``loss_fn`` may return a constant for an empty
+  strip (more ranks than tile rows, zero-weight rows of a balanced split): such a loss has no path to the strip
+  image.  ``ran`` is the marker the exchange's backward sets (``ExchangePlan.ran``); if it is still unset after the
+  loss's own backward pass, zero gradients are sent through instead.  (The first version made the dependency
+  unconditional with ``loss + 0 * g2[:1].sum() + 0 * f2[:1].sum()``: a dozen tiny launches and two full-size
+  gradient additions per step, on every rank, for a case that almost never occurs.)"""
+  if loss.requires_grad:
+    loss.backward()
+  if ran is not None and not ran.get('backward'):
+    tensors = [t for t in (g2, f2) if t.requires_grad]
+    if tensors:
+      torch.autograd.backward(tensors, [torch.zeros_like(t) for t in tensors])
 
 
 def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, config: RasterConfig,
@@ -132,8 +134,10 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
   px_rows = (rows[0] * ts, min(rows[1] * ts, camera_params.image_size[1]))
   loss = loss_fn(rendering.image, px_rows)
   if backward and (g2.requires_grad or f2.requires_grad):
-    # participation in the all-reduce below must not depend on what loss_fn returned on this rank
-    _tie_to_exchange(loss, g2, f2).backward()
+    # participation in the all-reduce below does not depend on what loss_fn returned on this rank: a constant
+    # loss simply contributes zeros
+    if loss.requires_grad:
+      loss.backward()
     gp = g2.grad if g2.grad is not None else torch.zeros_like(g2)
     gf = f2.grad if f2.grad is not None else torch.zeros_like(f2)
     gp, gf = allreduce_boundary_grads(gp, gf, group)
@@ -242,8 +246,8 @@ class _StripExchange(torch.autograd.Function):
   + sum of the copies of each local splat."""
 
   @staticmethod
-  def forward(ctx, gaussians2d, features, rows, send_index, route, send_counts, recv_counts, group, exchange):
-    ctx.route = route
+  def forward(ctx, gaussians2d, features, rows, send_index, route, send_counts, recv_counts, group, exchange, ran):
+    ctx.route, ctx.ran = route, ran
     ctx.send_index, ctx.send_counts, ctx.recv_counts = send_index, send_counts, recv_counts
     ctx.group, ctx.exchange, ctx.n, ctx.f = group, exchange, gaussians2d.shape[0], features.shape[1]
     recv = exchange(rows, send_counts, recv_counts, group)
@@ -253,6 +257,8 @@ class _StripExchange(torch.autograd.Function):
 
   @staticmethod
   def backward(ctx, grad_g2, grad_f2, _grad_d, _grad_ids):
+    if ctx.ran is not None:
+      ctx.ran['backward'] = True
     m = int(sum(ctx.recv_counts))
     dev_like = grad_g2 if grad_g2 is not None else grad_f2
     if grad_g2 is None:
@@ -268,18 +274,19 @@ class _StripExchange(torch.autograd.Function):
       _lib.check(lib.ms_strip_return_grads(_lib.ptr(back), _lib.ptr(ctx.send_index), _lib.ptr(ctx.route), ctx.f, back.shape[0],
                                            _lib.ptr(gp), _lib.ptr(gf), _lib.current_stream(back.device)),
                  'ms_strip_return_grads')
-      return gp, gf, None, None, None, None, None, None, None
+      return gp, gf, None, None, None, None, None, None, None, None
     grad = back.new_zeros((ctx.n, 7 + ctx.f))
     grad.index_add_(0, ctx.send_index, back)
-    return grad[:, :7].contiguous(), grad[:, 7:].contiguous(), None, None, None, None, None, None, None
+    return grad[:, :7].contiguous(), grad[:, 7:].contiguous(), None, None, None, None, None, None, None, None
 
 
 class ExchangePlan:
   """What one forward exchange decided: reusable to send per-splat rows of the strip back to their owners."""
 
-  def __init__(self, send_index, route, send_counts, recv_counts, group, exchange, n):
+  def __init__(self, send_index, route, send_counts, recv_counts, group, exchange, n, ran=None):
     self.send_index, self.route, self.send_counts, self.recv_counts = send_index, route, send_counts, recv_counts
     self.group, self.exchange, self.n = group, exchange, n
+    self.ran = ran if ran is not None else {}      # 'backward': set once the reverse exchange of this step has run
 
 
 def return_to_owners(plan: ExchangePlan, rows: torch.Tensor) -> torch.Tensor:
@@ -380,11 +387,12 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
     rows = torch.cat([g2d, feats, dep.to(g2d.dtype).unsqueeze(1), gid.to(id_type).view(g2d.dtype).unsqueeze(1)],
                      dim=1)[send_index]
 
+  ran = {}
   g2, f2, d, gid = _StripExchange.apply(gaussians2d, features, rows, send_index, route if kernels else None,
-                                        send_counts, recv_counts, group, exchange)
+                                        send_counts, recv_counts, group, exchange, ran)
   d = d.reshape((-1,) + tuple(depths.shape[1:]))
   if return_plan:
-    return g2, f2, d, gid, ExchangePlan(send_index, route if kernels else None, send_counts, recv_counts, group, exchange, n)
+    return g2, f2, d, gid, ExchangePlan(send_index, route if kernels else None, send_counts, recv_counts, group, exchange, n, ran)
   return g2, f2, d, gid
 
 
@@ -449,7 +457,7 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
   if backward and (g2.requires_grad or f2.requires_grad):
     # the reverse all-to-all in _StripExchange.backward is a collective: every rank runs it, also one whose
     # loss_fn returned a constant (empty strip)
-    _tie_to_exchange(loss, g2, f2).backward()
+    backward_through_exchange(loss, g2, f2, plan.ran)
 
   if point_stats is not None and (config.compute_visibility or config.compute_point_heuristic):
     # after the backward pass: the split heuristics are accumulated there

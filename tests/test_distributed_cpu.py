@@ -172,7 +172,7 @@ def _constant_loss_worker(rank, world, port, ret):
   dist.init_process_group('gloo', rank=rank, world_size=world)
   try:
     from taichi_splatting_amd import RasterConfig
-    from taichi_splatting_amd.distributed import shard_range, exchange_to_strips, _tie_to_exchange
+    from taichi_splatting_amd.distributed import shard_range, exchange_to_strips, backward_through_exchange
     from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
     from taichi_splatting_amd.testing import random_2d_gaussians
     torch.manual_seed(0)
@@ -184,11 +184,13 @@ def _constant_loss_worker(rank, world, port, ret):
     b, e = shard_range(p_full.shape[0], world, rank)
     p = p_full[b:e].clone().requires_grad_(True)
     f = f_full[b:e].clone().requires_grad_(True)
-    g2, f2, d2, gid2 = exchange_to_strips(p, f, d_full[b:e], size, RasterConfig(), bounds, global_index=torch.arange(b, e))
-    # what a loss_fn does on an empty strip: a constant.  Without the tie this rank would skip the reverse
-    # all-to-all inside backward() and rank 0 would hang in it.
+    g2, f2, d2, gid2, plan = exchange_to_strips(p, f, d_full[b:e], size, RasterConfig(), bounds, global_index=torch.arange(b, e),
+                                                return_plan=True)
+    # what a loss_fn does on an empty strip: a constant.  Without the zero-gradient pass this rank would skip the
+    # reverse all-to-all inside backward() and rank 0 would hang in it.
     loss = (g2.sum() + 2 * f2.sum()) if rank == 0 else torch.zeros(())
-    _tie_to_exchange(loss, g2, f2).backward()
+    backward_through_exchange(loss, g2, f2, plan.ran)
+    assert plan.ran.get('backward')
     visible = p.grad.abs().sum(dim=1) > 0
     ok = (torch.all(p.grad[visible] == 1.0) and torch.all(f.grad[visible] == 2.0) and int(visible.sum()) > 0
           and (rank == 0 or g2.shape[0] == 0))
