@@ -115,10 +115,12 @@ def render_strip_step(gaussians: Gaussians3D, camera_params: CameraParams, confi
   if world_size is None:
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1
 
-  # per-gaussian stages: replicated
+  # per-gaussian stages: replicated (the camera position is its own small launch: issued before the visible-count
+  # synchronisation of the projection, not after it)
+  camera_position = camera_params.camera_position if use_sh else None
   gaussians2d, depths, indexes = project_to_image(gaussians, camera_params, config)
   if use_sh:
-    features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_params.camera_position, unique_indexes=True)
+    features = evaluate_sh_at(gaussians.feature, gaussians.position.detach(), indexes, camera_position, unique_indexes=True)
   else:
     features = gaussians.feature[indexes]
 
@@ -425,12 +427,13 @@ def render_sharded_step(shard: Gaussians3D, camera_params: CameraParams, config:
   if world_size is None:
     world_size = dist.get_world_size(group) if dist.is_initialized() else 1
 
+  # the camera position is its own small launch: issued before the synchronisations below, not between them
+  camera_position = camera_params.camera_position if use_sh else None
   gaussians2d, depths, indexes = project_to_image(shard, camera_params, config)
 
   def features():
     if use_sh:
-      return evaluate_sh_at(shard.feature, shard.position.detach(), indexes, camera_params.camera_position,
-                            unique_indexes=True)
+      return evaluate_sh_at(shard.feature, shard.position.detach(), indexes, camera_position, unique_indexes=True)
     return shard.feature[indexes]
 
   ts = config.tile_size
