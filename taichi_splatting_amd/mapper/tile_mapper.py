@@ -66,9 +66,10 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
       depths = depths.to(torch.float32)
     v = points.shape[0]
 
-    tile_ranges = torch.zeros((*tile_shape, 2), dtype=torch.int32, device=device)
+    # ms_find_ranges writes every entry (zero fill + ranges): only the early returns need zeros from here
+    tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=device)
     if v == 0:
-      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
+      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
 
     def scratch(nbytes):
       return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
@@ -111,7 +112,7 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
       raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
                           "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
     if total == 0:
-      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges
+      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
 
     # 3. emit (tile id, point) in depth order; 4. STABLE sort on the tile id bits only
     keys = torch.empty((total,), dtype=torch.int32, device=device)
