@@ -37,7 +37,7 @@ def test_strips_compose_to_full_frame(world, dtype):
     rendering, _ = render_strip_step(part, cam, cfg, lambda img, px: (img * G).sum(), use_sh=True,
                                      rank=rank, world_size=world)
     y0, y1 = rows[0] * 16, min(rows[1] * 16, size[1])
-    assert float(rendering.image[:y0].abs().sum()) == 0 and float(rendering.image[y1:].abs().sum()) == 0
+    assert float(rendering.image.detach()[:y0].abs().sum()) == 0 and float(rendering.image.detach()[y1:].abs().sum()) == 0
     image[y0:y1] = rendering.image[y0:y1]
     grads = [part.position.grad, part.log_scaling.grad, part.rotation.grad, part.alpha_logit.grad, part.feature.grad]
     sums = grads if sums is None else [a + b for a, b in zip(sums, grads)]
