@@ -46,7 +46,7 @@
 namespace ms {
 
 #if MS_SCAN_STATS
-__device__ unsigned long long g_scan_stats[10];
+__device__ unsigned long long g_scan_stats[12];
 #endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
@@ -473,6 +473,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           if (lane == 0) {
             atomicAdd(&g_scan_stats[2], 1ull);                                           // chunks
             atomicAdd(&g_scan_stats[3], (unsigned long long)min(64, n - c0));             // filled lanes
+            if (n - c0 <= 16) atomicAdd(&g_scan_stats[10], 1ull);                         // chunks of <= 16 splats
+            else if (n - c0 <= 32) atomicAdd(&g_scan_stats[11], 1ull);                    // chunks of 17..32 splats
             atomicAdd(&g_scan_stats[4], (unsigned long long)steps_run);                  // executed pixel steps
             atomicAdd(&g_scan_stats[5], (unsigned long long)lanes_contrib);              // contributing (pixel, splat) pairs
           }
@@ -629,8 +631,8 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
 
 #if MS_SCAN_STATS
 extern "C" int ms_debug_scan_stats(unsigned long long* out10, int reset) {
-  if (out10) (void)hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_scan_stats), 10 * sizeof(unsigned long long));
-  if (reset) { unsigned long long z[10] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
+  if (out10) (void)hipMemcpyFromSymbol(out10, HIP_SYMBOL(g_scan_stats), 12 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_stats), z, sizeof(z)); }
   return 0;
 }
 #endif

@@ -96,12 +96,13 @@ def main():
     old(); new_main(); new_fin()
     torch.cuda.synchronize()
     if stats_fn is not None:
-      out = (ctypes.c_ulonglong * 10)()
+      out = (ctypes.c_ulonglong * 12)()
       stats_fn(ctypes.cast(out, ctypes.c_void_p), 1)
       visits, hits, chunks, lanes, steps, pairs = [int(v) for v in out[:6]]
       print(f"stats: (wave,batch) visits={visits} (sub-patch,splat) hits={hits} ({hits / o2p.shape[0]:.2f}/overlap) "
             f"chunks={chunks} fill={lanes / max(chunks, 1):.1f}/64 steps={steps} ({steps / max(chunks, 1):.1f}/chunk) "
             f"contributing pairs={pairs} ({pairs / max(steps, 1):.1f}/step)")
+      print(f"stats: chunks of <= 16 splats {int(out[10])} ({int(out[10]) / max(chunks, 1):.3f}), of 17..32 splats {int(out[11])} ({int(out[11]) / max(chunks, 1):.3f})")
       if out[9]:
         print(f"stats: wave balance inside a workgroup: chunks run {int(out[8])}, slots until the batch barrier {int(out[9])} "
               f"-> {int(out[8]) / int(out[9]):.3f} of the barrier-to-barrier wave time is blend work")
