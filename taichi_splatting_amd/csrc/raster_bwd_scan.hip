@@ -94,14 +94,6 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// v_min_f32 with the wave-uniform operand read straight from its SGPR (min_f32() of raster_common.h takes two
-// VGPRs and costs a v_mov_b32 per use when one side is a kernel argument)
-__device__ __forceinline__ float min_f32_uniform(float a, float uniform_b) {
-  float r;
-  asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform_b));
-  return r;
-}
-
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 // 48-byte LDS record of a staged splat:

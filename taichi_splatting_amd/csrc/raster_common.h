@@ -176,13 +176,30 @@ __device__ __forceinline__ float wave_reduce4(const float (&v)[4], bool b0, bool
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf (inputs are never sNaN here)
+// v_min_f32 without the canonicalising v_max hipcc puts in front of fminf (inputs are never sNaN here).
+// NOT directly after the transcendental instruction that produces an operand: see clamp_alpha().
 __device__ __forceinline__ float min_f32(float a, float b) {
   float r;
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 
+
+// v_min_f32 with the wave-uniform operand read straight from its SGPR (min_f32() takes two
+// VGPRs and costs a v_mov_b32 per use when one side is a kernel argument)
+__device__ __forceinline__ float min_f32_uniform(float a, float uniform_b) {
+  float r;
+  asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(uniform_b));
+  return r;
+}
+
+// min(e, clamp) for e >= 0 as ONE compiler-visible instruction (v_med3_f32 e, 0, clamp).  The inline-assembly
+// v_min_f32 above must not directly follow the v_exp_f32 that produces its operand: gfx950 needs a wait state between
+// a transcendental result and its VALU use, the hazard recogniser does not look into inline assembly, and half of the
+// lanes then read the stale register (seen in the forward's hit loop once nothing else was scheduled in between).
+__device__ __forceinline__ float clamp_alpha(float e, float clamp_max_alpha) {
+  return __builtin_amdgcn_fmed3f(e, 0.0f, clamp_max_alpha);
+}
 
 template <int TS> struct TileGeom {
   static constexpr int THREADS = TS * TS;

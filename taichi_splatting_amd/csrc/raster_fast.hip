@@ -109,13 +109,13 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
           for (int u = 0; u < 4; ++u) {
             if (m != 0) {                                   // wave-uniform
               const int b = __builtin_ctzll(m);
-              m &= m - 1;
+              asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
               bq[u] = b;
               const float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1];
               const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
               const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
               const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
-              const float a = min_f32(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
+              const float a = clamp_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
               const float w = a > rp.alpha_threshold ? a * T : 0.0f;
               T -= w;
               c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
@@ -130,30 +130,22 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         }
         continue;
       }
-      int b = __builtin_ctzll(m);
-      m &= m - 1;
-      // the forward uses 40 of the record's 48 bytes: the third read is 64 bits (the LDS pipe is ~80 % busy here)
-      float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1];
-      float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
-      while (true) {
-        const bool more = m != 0;
-        const int nb = more ? __builtin_ctzll(m) : b;
-        m &= m - 1;
-        // prefetch the next hit's record (re-reads the current one on the last iteration)
-        const float4 n0 = s_rec[(r + nb) * 3 + 0], n1 = s_rec[(r + nb) * 3 + 1];
-        const float2 n2 = *reinterpret_cast<const float2*>(&s_rec[(r + nb) * 3 + 2]);
-
+      // plain hit loop: one scalar bit scan + bit clear per hit (the compiler turns a hand-written prefetch of the
+      // next record into a dozen scalar instructions per hit and drops the prefetch itself)
+      while (m != 0) {
+        const int b = __builtin_ctzll(m);
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+        // the forward uses 40 of the record's 48 bytes: the third read is 64 bits
+        const float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1];
+        const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
         // (X, Y) = basis * (pixel - mean), expanded around the tile centre (write_records<true>)
         const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
         const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
         // alpha * g in one exponential: A..D pre-scaled, q1.z = -log2(alpha) (write_records<true>)
-        const float a = min_f32(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
+        const float a = clamp_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
         const float w = a > rp.alpha_threshold ? a * T : 0.0f;
         T -= w;
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
-
-        if (!more) break;
-        b = nb; q0 = n0; q1 = n1; q2 = n2;
       }
     }
   }

@@ -67,7 +67,7 @@ def main():
       vis_off = int(((out32.visibility.double() - out64.visibility).abs() > 1e-3 * max(vis_scale, 1e-30)).sum())
       fwd_typical = float((out32.image.double() - out64.image).abs().median())
       if not (torch.isfinite(out32.image).all() and px_off <= px_allowed and vis_off <= max(24, int(2e-3 * n)) and fwd_typical <= 1e-5
-              and torch.equal(out32.image, image)):
+              and float((out32.image - image).abs().max()) <= 2e-6):     # with and without visibility: same blend
         tag = (f"seed {seed} forward: tile {tile} {w}x{h} n={n} K={o2p.shape[0]} scale={scale:.2f} thr={cfg.alpha_threshold:.3f} "
                f"pixels off={px_off} (allowed {px_allowed}) visibility off={vis_off} median={fwd_typical:.1e}")
         failures.append(tag)
