@@ -251,11 +251,10 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       bool hit = false;
       if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
       unsigned long long m = __ballot(hit);
-      const int rec_index = j * 3;
       while (m) {
         const int b = __builtin_ctzll(m);
-        m &= ~(1ull << b);
-        const int ri = __builtin_amdgcn_readlane(rec_index, b);
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+        const int ri = (r + b) * 3;
         const float4 q0 = s_rec[ri + 0], q1 = s_rec[ri + 1], q2 = s_rec[ri + 2];
 
         const float A = q0.z, B = q0.w, C = q1.x, D = q1.y, alpha_pt = q1.z;
