@@ -203,10 +203,18 @@ radix_upsweep_kernel(const KeyT* __restrict__ keys, int64_t n, int shift, unsign
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS + lane;
+  if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n) {        // every item of the block exists: no bounds checks
+    KeyT k[RS_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) k[j] = keys[base + j * 64];
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; ++j) atomicAdd(&cnt[wave][key_digit(k[j], shift, mask)], 1u);
+  } else {
 #pragma unroll 4
-  for (int j = 0; j < RS_ROUNDS; ++j) {
-    const int64_t i = base + j * 64;
-    if (i < n) atomicAdd(&cnt[wave][key_digit(keys[i], shift, mask)], 1u);
+    for (int j = 0; j < RS_ROUNDS; ++j) {
+      const int64_t i = base + j * 64;
+      if (i < n) atomicAdd(&cnt[wave][key_digit(keys[i], shift, mask)], 1u);
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
@@ -236,14 +244,25 @@ radix_row_scan_kernel(int32_t* __restrict__ hist, int64_t num_blocks, int32_t* _
   if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(RS_THREADS)
-radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
-                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
-                       unsigned mask, const int32_t* __restrict__ hist_scanned,
-                       const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
-  __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
-  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+template <typename KeyT> struct DownsweepShared {
+  unsigned cnt[RS_WAVES][RS_RADIX];
+  int scan[4];
+  unsigned digit_local[RS_RADIX];     // block-local start of digit d
+  unsigned digit_global[RS_RADIX];    // global start of this block's run of digit d
+  KeyT keys[RS_TILE];
+  int32_t vals[RS_TILE];
+};
+
+// FULL: every one of the block's RS_TILE items exists (all blocks but the last): no bounds checks at all.  With
+// them each of the 32 loads of a thread sat in its own EXEC-masked block behind a 64-bit compare, and the ranking and
+// the scatter carried a validity flag per item.
+template <typename KeyT, bool FULL>
+__device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const KeyT* __restrict__ keys_in,
+                                                const int32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+                                                int32_t* __restrict__ vals_out, int64_t n, int shift, unsigned mask,
+                                                const int32_t* __restrict__ hist_scanned,
+                                                const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
+  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&sh.cnt[0][0])[i] = 0;
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -257,7 +276,7 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const int64_t i = base + j * 64;
-    const bool valid = i < n;
+    const bool valid = FULL || i < n;
     k[j] = valid ? keys_in[i] : (KeyT)0;
     v[j] = valid ? vals_in[i] : 0;
   }
@@ -265,10 +284,10 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const int64_t i = base + j * 64;
-    const bool valid = i < n;
+    const bool valid = FULL || i < n;
     const unsigned d = key_digit(k[j], shift, mask);
     // match-any over the 8 digit bits: peers = lanes holding the same digit
-    unsigned long long peers = __ballot(valid);
+    unsigned long long peers = FULL ? ~0ull : __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       const bool bit = (d >> b) & 1u;
@@ -278,10 +297,10 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
     const unsigned below = (unsigned)__popcll(peers & lanes_below);
     unsigned prev = 0;
     if (valid) {
-      prev = cnt[wave][d];
+      prev = sh.cnt[wave][d];
     }
     __builtin_amdgcn_wave_barrier();
-    if (valid && below == 0) cnt[wave][d] = prev + (unsigned)__popcll(peers);
+    if (valid && below == 0) sh.cnt[wave][d] = prev + (unsigned)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
     rank[j] = prev + below;
   }
@@ -290,58 +309,69 @@ radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restri
   // per digit: exclusive offsets of the waves inside the block (cnt[w][d] <- local start of wave w's
   // run of digit d), the block-local start of the digit (exclusive scan over the 256 digit totals)
   // and the global start of this block's run of the digit
-  __shared__ int s_scan[4];
-  __shared__ unsigned s_digit_local[RS_RADIX];    // block-local start of digit d
-  __shared__ unsigned s_digit_global[RS_RADIX];   // global start of this block's run of digit d
   {
     const int d = threadIdx.x;                    // RS_THREADS == RS_RADIX
     unsigned total = 0;
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) total += cnt[w][d];
+    for (int w = 0; w < RS_WAVES; ++w) total += sh.cnt[w][d];
     int block_total;
-    const unsigned local = (unsigned)block_exclusive_scan((int)total, s_scan, &block_total);
+    const unsigned local = (unsigned)block_exclusive_scan((int)total, sh.scan, &block_total);
     unsigned run = local;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) {
-      const unsigned c = cnt[w][d];
-      cnt[w][d] = run;
+      const unsigned c = sh.cnt[w][d];
+      sh.cnt[w][d] = run;
       run += c;
     }
-    s_digit_local[d] = local;
+    sh.digit_local[d] = local;
     // global start of the digit = items of all smaller digits (256-entry scan, done by every block for itself)
     // + items of this digit in earlier blocks (radix_row_scan_kernel)
     int all_items;
-    const unsigned digit_base = (unsigned)block_exclusive_scan(digit_totals[d], s_scan, &all_items);
-    s_digit_global[d] = digit_base + (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
+    const unsigned digit_base = (unsigned)block_exclusive_scan(digit_totals[d], sh.scan, &all_items);
+    sh.digit_global[d] = digit_base + (unsigned)hist_scanned[(int64_t)d * num_blocks + blockIdx.x];
   }
   __syncthreads();
 
   // reorder through LDS so the global scatter is written in digit order: consecutive threads then
   // write consecutive addresses inside each digit run (coalesced 64 B+ segments instead of one
   // transaction per lane)
-  __shared__ KeyT s_keys[RS_TILE];
-  __shared__ int32_t s_vals[RS_TILE];
 #pragma unroll
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const int64_t i = base + j * 64;
-    if (i < n) {
+    if (FULL || i < n) {
       const unsigned d = key_digit(k[j], shift, mask);
-      const unsigned lp = cnt[wave][d] + rank[j];
-      s_keys[lp] = k[j];
-      s_vals[lp] = v[j];
+      const unsigned lp = sh.cnt[wave][d] + rank[j];
+      sh.keys[lp] = k[j];
+      sh.vals[lp] = v[j];
     }
   }
   __syncthreads();
   const int64_t block_base = (int64_t)blockIdx.x * RS_TILE;
-  const int block_items = (n - block_base) < RS_TILE ? (int)(n - block_base) : RS_TILE;
-#pragma unroll 4
-  for (int idx = threadIdx.x; idx < block_items; idx += RS_THREADS) {
-    const KeyT key = s_keys[idx];
-    const unsigned d = key_digit(key, shift, mask);
-    const int64_t pos = (int64_t)s_digit_global[d] + (idx - s_digit_local[d]);
-    keys_out[pos] = key;
-    vals_out[pos] = s_vals[idx];
+  const int block_items = FULL ? RS_TILE : (int)(n - block_base);
+#pragma unroll
+  for (int j = 0; j < RS_ROUNDS; ++j) {
+    const int idx = (int)threadIdx.x + j * RS_THREADS;
+    if (FULL || idx < block_items) {
+      const KeyT key = sh.keys[idx];
+      const unsigned d = key_digit(key, shift, mask);
+      const int64_t pos = (int64_t)sh.digit_global[d] + (idx - sh.digit_local[d]);
+      keys_out[pos] = key;
+      vals_out[pos] = sh.vals[idx];
+    }
   }
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(RS_THREADS)
+radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
+                       unsigned mask, const int32_t* __restrict__ hist_scanned,
+                       const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
+  __shared__ DownsweepShared<KeyT> sh;
+  if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n)
+    downsweep_block<KeyT, true>(sh, keys_in, vals_in, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
+  else
+    downsweep_block<KeyT, false>(sh, keys_in, vals_in, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
 }
 
 template <typename KeyT>

@@ -378,10 +378,11 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
     rows = g2d.new_empty((total, 9 + f))
     send_index = torch.empty((total,), dtype=torch.int64, device=g2d.device)
     ids = global_index.to(torch.int64).contiguous() if global_index is not None else None
-    _lib.check(lib.ms_strip_route_pack(_lib.ptr(g2d), _lib.ptr(feats), _lib.ptr(dep), _lib.ptr(ids), f, n,
-                                       world, int(index_offset), _lib.ptr(route), _lib.ptr(block_offsets),
-                                       _lib.ptr(send_counts_t), _lib.ptr(rows), _lib.ptr(send_index), stream),
-               'ms_strip_route_pack')
+    if total > 0:         # nothing to pack when no local splat reaches any strip (all of them below the alpha gate)
+      _lib.check(lib.ms_strip_route_pack(_lib.ptr(g2d), _lib.ptr(feats), _lib.ptr(dep), _lib.ptr(ids), f, n,
+                                         world, int(index_offset), _lib.ptr(route), _lib.ptr(block_offsets),
+                                         _lib.ptr(send_counts_t), _lib.ptr(rows), _lib.ptr(send_index), stream),
+                 'ms_strip_route_pack')
   else:
     send_index, _ = expand_routes(first, copies, total)
     gid = (global_index if global_index is not None else torch.arange(n, device=g2d.device)) + index_offset
