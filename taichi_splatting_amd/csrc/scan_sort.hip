@@ -286,14 +286,19 @@ __device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const
     const int64_t i = base + j * 64;
     const bool valid = FULL || i < n;
     const unsigned d = key_digit(k[j], shift, mask);
-    // match-any over the 8 digit bits: peers = lanes holding the same digit
-    unsigned long long peers = FULL ? ~0ull : __ballot(valid);
+    // match-any over the 8 digit bits: peers = lanes holding the same digit.  Per bit: the lane's bit as a 0 / ~0
+    // mask (one v_bfe_i32), its ballot, and per 32-lane half  peers &= ~(ballot ^ mask)  (one v_bitop3_b32 each) —
+    // four VALU instructions per bit; the 64-bit select form compiled to nine.
+    const unsigned long long valid_lanes = FULL ? ~0ull : __ballot(valid);
+    unsigned peers_lo = (unsigned)valid_lanes, peers_hi = (unsigned)(valid_lanes >> 32);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+      const int m = __builtin_amdgcn_sbfe((int)d, b, 1);          // 0 or -1
+      const unsigned long long bal = __ballot(m != 0);
+      peers_lo &= ~((unsigned)bal ^ (unsigned)m);
+      peers_hi &= ~((unsigned)(bal >> 32) ^ (unsigned)m);
     }
+    const unsigned long long peers = ((unsigned long long)peers_hi << 32) | peers_lo;
     const unsigned below = (unsigned)__popcll(peers & lanes_below);
     unsigned prev = 0;
     if (valid) {
