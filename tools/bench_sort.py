@@ -5,7 +5,10 @@ sys.path.insert(0, '.')
 from taichi_splatting_amd import _lib
 lib = _lib.load()
 dev = torch.device('cuda', 0)
-for n, bits in ((12_760_302, 14), (6_000_000, 32)):
+CASES = ((12_760_302, 14), (6_000_000, 32))
+if len(sys.argv) > 1:                      # python tools/bench_sort.py k | v
+  CASES = CASES[:1] if sys.argv[1] == 'k' else CASES[1:]
+for n, bits in CASES:
   torch.manual_seed(0)
   keys = torch.randint(0, 2 ** min(bits, 31) - 1, (n,), dtype=torch.int32, device=dev)
   vals = torch.arange(n, dtype=torch.int32, device=dev)

@@ -7,18 +7,19 @@ from collections import defaultdict
 from pathlib import Path
 
 root = Path(sys.argv[1])
+wanted = sys.argv[2] if len(sys.argv) > 2 else 'raster'      # substring of the kernel names to keep
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 for f in sorted(root.glob('*/**/*counter_collection.csv')):
   for row in csv.DictReader(open(f)):
     name = row['Kernel_Name'].split('(')[0]
-    if 'raster' not in name:
+    if wanted not in name:
       continue
     acc[name][row['Counter_Name']].append(float(row['Counter_Value']))
 for f in sorted(root.glob('*/**/*kernel_trace.csv')):
   for row in csv.DictReader(open(f)):
     name = row['Kernel_Name'].split('(')[0]
-    if 'raster' in name:
+    if wanted in name:
       dur[name].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
 out = {}
 for name, counters in acc.items():
