@@ -129,6 +129,13 @@ int ms_tile_count(const float* points7, const int32_t* order, int64_t v, int ima
 int ms_depth_sort_keys(const void* depth, int64_t v, int depth16, double ndc_near, double ndc_far,
                        uint32_t* out_keys, int32_t* out_values, int dtype, void* stream);
 
+/* ms_depth_sort_keys + ms_radix_sort_pairs (32 bit keys, all 32 or 16 bits) in one call: the first radix pass makes
+ * its keys from `depth` on the fly and takes the item index as value, so no key / value arrays exist before the
+ * first scatter.  out_order[j] = index of the j-th gaussian in (depth, index) order, out_sorted_keys its key.
+ * tmp: call with tmp == NULL for *tmp_bytes (same size as ms_radix_sort_pairs for v 4-byte keys). */
+int ms_depth_argsort(const void* depth, int64_t v, int depth16, double ndc_near, double ndc_far, int dtype,
+                     uint32_t* out_sorted_keys, int32_t* out_order, void* tmp, size_t* tmp_bytes, void* stream);
+
 /* cuda_lib.full_cumsum (cuda_lib/full_cumsum.cu:17-67): exclusive scan of n int32 into out[0..n],
  * out[n] = total.  If total_host is not NULL it must be pinned, device-visible host memory and
  * receives the total as well (valid after the stream is synchronised). */

@@ -105,4 +105,19 @@ __device__ __forceinline__ void block_sum_commit(const T (&v)[NV], T* __restrict
   }
 }
 
+// 32 bit sort key of the depth pre-sort: float bits (non-negative depths keep their order) or the 16 bit quantisation
+// of make_sort_key (tile_mapper.py:55-61).  near_plane > 0 fuses ndc_depth (torch_lib/projection.py:120-123,
+// renderer.py:67): evaluated in double from the depth's own precision, then rounded once to the float the key is made of.
+template <typename T>
+__device__ __forceinline__ uint32_t depth_sort_key(T depth, int depth16, double near_plane, double far_plane) {
+  float d;
+  if (near_plane > 0.0) {
+    const double dd = (double)depth;
+    d = (float)(1.0 - (1.0 / dd - 1.0 / far_plane) / (1.0 / near_plane - 1.0 / far_plane));
+  } else {
+    d = (float)depth;
+  }
+  return depth16 ? (uint32_t)(fminf(fmaxf(d, 0.0f), 1.0f) * 65535.0f) : __float_as_uint(d);
+}
+
 }  // namespace ms

@@ -89,14 +89,7 @@ depth_keys_kernel(const T* __restrict__ depth, int64_t v, int depth16, double ne
                   uint32_t* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
-  float d;
-  if (near_plane > 0.0) {
-    const double dd = (double)depth[i];
-    d = (float)(1.0 - (1.0 / dd - 1.0 / far_plane) / (1.0 / near_plane - 1.0 / far_plane));
-  } else {
-    d = (float)depth[i];
-  }
-  keys[i] = depth16 ? (uint32_t)(fminf(fmaxf(d, 0.0f), 1.0f) * 65535.0f) : __float_as_uint(d);
+  keys[i] = depth_sort_key(depth[i], depth16, near_plane, far_plane);
   values[i] = (int32_t)i;
 }
 

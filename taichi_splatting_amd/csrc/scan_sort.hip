@@ -194,9 +194,27 @@ __device__ __forceinline__ unsigned key_digit(KeyT k, int shift, unsigned mask) 
   return (unsigned)(k >> shift) & mask;
 }
 
-template <typename KeyT>
+// Where a pass reads its (key, value) pairs from.  PlainPairs: two arrays.  DepthPairs: the first pass of the mapper's
+// depth pre-sort makes its keys on the fly — float bits of the (ndc) depth or the 16-bit quantisation, exactly
+// depth_sort_key() of mapper.hip's depth_keys_kernel — and the value is the item's index: no key / value arrays are
+// written or read before the first scatter (ms_depth_argsort).
+template <typename KeyT> struct PlainPairs {
+  const KeyT* keys;
+  const int32_t* vals;
+  __device__ __forceinline__ KeyT key(int64_t i) const { return keys[i]; }
+  __device__ __forceinline__ int32_t val(int64_t i) const { return vals[i]; }
+};
+template <typename T> struct DepthPairs {
+  const T* depth;
+  int depth16;
+  double near_plane, far_plane;
+  __device__ __forceinline__ uint32_t key(int64_t i) const { return depth_sort_key(depth[i], depth16, near_plane, far_plane); }
+  __device__ __forceinline__ int32_t val(int64_t i) const { return (int32_t)i; }
+};
+
+template <typename KeyT, typename Source>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_upsweep_kernel(const KeyT* __restrict__ keys, int64_t n, int shift, unsigned mask,
+radix_upsweep_kernel(const Source src, int64_t n, int shift, unsigned mask,
                      int32_t* __restrict__ hist, int64_t num_blocks) {
   __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
@@ -206,14 +224,14 @@ radix_upsweep_kernel(const KeyT* __restrict__ keys, int64_t n, int shift, unsign
   if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n) {        // every item of the block exists: no bounds checks
     KeyT k[RS_ROUNDS];
 #pragma unroll
-    for (int j = 0; j < RS_ROUNDS; ++j) k[j] = keys[base + j * 64];
+    for (int j = 0; j < RS_ROUNDS; ++j) k[j] = src.key(base + j * 64);
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; ++j) atomicAdd(&cnt[wave][key_digit(k[j], shift, mask)], 1u);
   } else {
 #pragma unroll 4
     for (int j = 0; j < RS_ROUNDS; ++j) {
       const int64_t i = base + j * 64;
-      if (i < n) atomicAdd(&cnt[wave][key_digit(keys[i], shift, mask)], 1u);
+      if (i < n) atomicAdd(&cnt[wave][key_digit(src.key(i), shift, mask)], 1u);
     }
   }
   __syncthreads();
@@ -256,9 +274,8 @@ template <typename KeyT> struct DownsweepShared {
 // FULL: every one of the block's RS_TILE items exists (all blocks but the last): no bounds checks at all.  With
 // them each of the 32 loads of a thread sat in its own EXEC-masked block behind a 64-bit compare, and the ranking and
 // the scatter carried a validity flag per item.
-template <typename KeyT, bool FULL>
-__device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const KeyT* __restrict__ keys_in,
-                                                const int32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out,
+template <typename KeyT, bool FULL, typename Source>
+__device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const Source src, KeyT* __restrict__ keys_out,
                                                 int32_t* __restrict__ vals_out, int64_t n, int shift, unsigned mask,
                                                 const int32_t* __restrict__ hist_scanned,
                                                 const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
@@ -277,8 +294,8 @@ __device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const
   for (int j = 0; j < RS_ROUNDS; ++j) {
     const int64_t i = base + j * 64;
     const bool valid = FULL || i < n;
-    k[j] = valid ? keys_in[i] : (KeyT)0;
-    v[j] = valid ? vals_in[i] : 0;
+    k[j] = valid ? src.key(i) : (KeyT)0;
+    v[j] = valid ? src.val(i) : 0;
   }
 
 #pragma unroll
@@ -366,17 +383,17 @@ __device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const
   }
 }
 
-template <typename KeyT>
+template <typename KeyT, typename Source>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_downsweep_kernel(const KeyT* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
+radix_downsweep_kernel(const Source src,
                        KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
                        unsigned mask, const int32_t* __restrict__ hist_scanned,
                        const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
   __shared__ DownsweepShared<KeyT> sh;
   if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n)
-    downsweep_block<KeyT, true>(sh, keys_in, vals_in, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
+    downsweep_block<KeyT, true>(sh, src, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
   else
-    downsweep_block<KeyT, false>(sh, keys_in, vals_in, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
+    downsweep_block<KeyT, false>(sh, src, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
 }
 
 template <typename KeyT>
@@ -403,24 +420,20 @@ static SortTmp sort_tmp_layout(int64_t n, int key_bytes) {
   return t;
 }
 
-template <typename KeyT>
-static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, KeyT* keys_out,
-                                 int32_t* vals_out, int64_t n, int begin_bit, int end_bit, char* tmp,
-                                 hipStream_t s) {
+// `first` = where pass 0 reads its pairs (PlainPairs of the caller's arrays, or DepthPairs); later passes read the
+// ping-pong buffers.
+template <typename KeyT, typename First>
+static int radix_sort_passes(const First first, KeyT* keys_out, int32_t* vals_out, int64_t n, int begin_bit, int end_bit,
+                             char* tmp, hipStream_t s) {
   const int64_t blocks = div_up(n, RS_TILE);
   const SortTmp lay = sort_tmp_layout(n, sizeof(KeyT));
   int32_t* hist = (int32_t*)(tmp + lay.hist_off);
   int32_t* digit_totals = (int32_t*)(tmp + lay.scan_off);       // 256 ints
   KeyT* keys_alt = (KeyT*)(tmp + lay.keys_off);
   int32_t* vals_alt = (int32_t*)(tmp + lay.vals_off);
-
   const int passes = (end_bit - begin_bit + 7) / 8;
-  if (passes == 0) {
-    copy_pairs_kernel<KeyT><<<dim3((unsigned)div_up(n, 256)), dim3(256), 0, s>>>(keys_in, vals_in, keys_out, vals_out, n);
-    return 0;
-  }
-  const KeyT* src_k = keys_in;
-  const int32_t* src_v = vals_in;
+  const dim3 grid((unsigned)blocks), block(RS_THREADS);
+  PlainPairs<KeyT> src{nullptr, nullptr};
   for (int p = 0; p < passes; ++p) {
     const int shift = begin_bit + 8 * p;
     const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
@@ -428,15 +441,25 @@ static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, Ke
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     KeyT* dst_k = to_out ? keys_out : keys_alt;
     int32_t* dst_v = to_out ? vals_out : vals_alt;
-
-    radix_upsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(src_k, n, shift, mask, hist, blocks);
+    if (p == 0) radix_upsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, n, shift, mask, hist, blocks);
+    else radix_upsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, n, shift, mask, hist, blocks);
     radix_row_scan_kernel<<<dim3(RS_RADIX), dim3(SCAN_THREADS), 0, s>>>(hist, blocks, digit_totals);
-    radix_downsweep_kernel<KeyT><<<dim3((unsigned)blocks), dim3(RS_THREADS), 0, s>>>(
-        src_k, src_v, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
-    src_k = dst_k;
-    src_v = dst_v;
+    if (p == 0) radix_downsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
+    else radix_downsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
+    src = PlainPairs<KeyT>{dst_k, dst_v};
   }
   return 0;
+}
+
+template <typename KeyT>
+static int radix_sort_pairs_impl(const KeyT* keys_in, const int32_t* vals_in, KeyT* keys_out,
+                                 int32_t* vals_out, int64_t n, int begin_bit, int end_bit, char* tmp,
+                                 hipStream_t s) {
+  if ((end_bit - begin_bit + 7) / 8 == 0) {
+    copy_pairs_kernel<KeyT><<<dim3((unsigned)div_up(n, 256)), dim3(256), 0, s>>>(keys_in, vals_in, keys_out, vals_out, n);
+    return 0;
+  }
+  return radix_sort_passes<KeyT>(PlainPairs<KeyT>{keys_in, vals_in}, keys_out, vals_out, n, begin_bit, end_bit, tmp, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,6 +536,26 @@ extern "C" int ms_radix_sort_pairs(const void* keys_in, const int32_t* values_in
     radix_sort_pairs_impl<uint32_t>((const uint32_t*)keys_in, values_in, (uint32_t*)keys_out, values_out, n, begin_bit, end_bit, (char*)tmp, (hipStream_t)stream);
   else
     radix_sort_pairs_impl<uint64_t>((const uint64_t*)keys_in, values_in, (uint64_t*)keys_out, values_out, n, begin_bit, end_bit, (char*)tmp, (hipStream_t)stream);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_depth_argsort(const void* depth, int64_t v, int depth16, double ndc_near, double ndc_far,
+                               int dtype, uint32_t* out_sorted_keys, int32_t* out_order, void* tmp,
+                               size_t* tmp_bytes, void* stream) {
+  MS_CHECK_ARG(v >= 0, "v < 0");
+  MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
+  MS_CHECK_ARG(tmp_bytes != nullptr, "tmp_bytes is null");
+  const size_t need = sort_tmp_layout(v, 4).total;
+  if (tmp == nullptr) { *tmp_bytes = need; return 0; }
+  if (*tmp_bytes < need) { set_error("ms_depth_argsort: tmp too small (%zu < %zu)", *tmp_bytes, need); return MS_ERR_TMP_TOO_SMALL; }
+  if (v == 0) return 0;
+  MS_CHECK_ARG(depth && out_sorted_keys && out_order, "null pointer");
+  const int end_bit = depth16 ? 16 : 32;
+  if (dtype == MS_F32)
+    radix_sort_passes<uint32_t>(DepthPairs<float>{(const float*)depth, depth16, ndc_near, ndc_far}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
+  else
+    radix_sort_passes<uint32_t>(DepthPairs<double>{(const double*)depth, depth16, ndc_near, ndc_far}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -86,14 +86,19 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                                          ctypes.byref(nb), stream), "map_to_tiles")
       return keys_out, vals_out
 
-    # 1. depth pre-sort of the V gaussians (stable: ties keep point order): 32 bit keys, 4 radix
-    #    passes over V pairs (2 for depth16) instead of 4 of the 6 passes over the K overlaps
-    dkeys = torch.empty((v,), dtype=torch.int32, device=device)
-    dvals = torch.empty((v,), dtype=torch.int32, device=device)
+    # 1. depth pre-sort of the V gaussians (stable: ties keep point order): 32 bit keys, 4 radix passes over V pairs
+    #    (2 for depth16) instead of 4 of the 6 passes over the K overlaps; the first pass makes the keys from the
+    #    depths itself (ms_depth_argsort)
     near, far = (0.0, 0.0) if ndc_range is None else (float(ndc_range[0]), float(ndc_range[1]))
-    _lib.check(lib.ms_depth_sort_keys(depths.data_ptr(), v, int(use_depth16), near, far, dkeys.data_ptr(),
-                                      dvals.data_ptr(), _lib.dtype_code(depths.dtype), stream), "map_to_tiles")
-    _, order = sort_pairs(dkeys, dvals, 4, 16 if use_depth16 else 32)
+    sorted_keys = torch.empty((v,), dtype=torch.int32, device=device)
+    order = torch.empty((v,), dtype=torch.int32, device=device)
+    nb = ctypes.c_size_t(0)
+    _lib.check(lib.ms_depth_argsort(None, v, int(use_depth16), near, far, _lib.dtype_code(depths.dtype), None, None, None,
+                                    ctypes.byref(nb), stream), "map_to_tiles")
+    tmp = scratch(nb.value)
+    _lib.check(lib.ms_depth_argsort(depths.data_ptr(), v, int(use_depth16), near, far, _lib.dtype_code(depths.dtype),
+                                    sorted_keys.data_ptr(), order.data_ptr(), tmp.data_ptr(), ctypes.byref(nb), stream),
+               "map_to_tiles")
 
     # 2. overlap counts in depth order, exclusive scan, total K (the one host sync of the mapper)
     counts = torch.empty((v,), dtype=torch.int32, device=device)
