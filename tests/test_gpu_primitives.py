@@ -95,3 +95,35 @@ def test_morton_nan_and_empty():
   pts = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.5, float('inf'), 0.5]], device='cuda:0')
   codes = morton_sort.morton_codes(pts, 0.25)
   assert codes.shape == (3,) and int(codes[0]) == 0 and int(codes[1]) == 0b111000000   # cell (4, 4, 4)
+
+
+@pytest.mark.parametrize('n', [1, 63, 4096, 4097, 250_001])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('depth16', [False, True])
+@pytest.mark.parametrize('ndc', [False, True])
+def test_depth_argsort_equals_keys_then_stable_sort(n, dtype, depth16, ndc):
+  """ms_depth_argsort (keys made inside the first radix pass) against ms_depth_sort_keys + a stable torch sort"""
+  import ctypes
+  from taichi_splatting_amd import _lib
+  lib = _lib.load()
+  torch.manual_seed(n)
+  depth = (torch.rand(n, dtype=dtype) * (9.0 if ndc else 1.0) + (0.5 if ndc else 0.0)).to(DEV)
+  depth[::7] = depth[0].clone()                           # ties: broken by index
+  near, far = (0.25, 60.0) if ndc else (0.0, 0.0)
+  stream = _lib.current_stream(torch.device(DEV))
+  keys = torch.empty(n, dtype=torch.int32, device=DEV)
+  vals = torch.empty(n, dtype=torch.int32, device=DEV)
+  _lib.check(lib.ms_depth_sort_keys(depth.data_ptr(), n, int(depth16), near, far, keys.data_ptr(), vals.data_ptr(),
+                                    _lib.dtype_code(dtype), stream), "keys")
+  want_keys, want_order = torch.sort(keys.long() & 0xffffffff, stable=True)
+
+  nb = ctypes.c_size_t(0)
+  _lib.check(lib.ms_depth_argsort(None, n, int(depth16), near, far, _lib.dtype_code(dtype), None, None, None,
+                                  ctypes.byref(nb), stream), "size")
+  tmp = torch.empty(max(nb.value, 1), dtype=torch.uint8, device=DEV)
+  got_keys = torch.empty(n, dtype=torch.int32, device=DEV)
+  got_order = torch.empty(n, dtype=torch.int32, device=DEV)
+  _lib.check(lib.ms_depth_argsort(depth.data_ptr(), n, int(depth16), near, far, _lib.dtype_code(dtype),
+                                  got_keys.data_ptr(), got_order.data_ptr(), tmp.data_ptr(), ctypes.byref(nb), stream), "argsort")
+  assert torch.equal(got_order.long(), want_order)
+  assert torch.equal(got_keys.long() & 0xffffffff, want_keys)
