@@ -138,10 +138,10 @@ def stage_breakdown(g, cam, cfg, use_sh):
     def bwd():
       _lib.check(lib.ms_raster_bwd_moments(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
                                            image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, moments.data_ptr(),
-                                           0, 0, tiles_high, stream), "bench raster_bwd")
+                                           0, None, 0, tiles_high, stream), "bench raster_bwd")
 
     def fin():
-      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), moments.data_ptr(), 0, g2d.shape[0], gp.data_ptr(),
+      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), moments.data_ptr(), 0, None, g2d.shape[0], gp.data_ptr(),
                                                 gf.data_ptr(), None, stream), "bench raster finalize")
     out['raster_bwd'] = cuda_time_ms(bwd, iters=10, warmup=2)
     out['raster_bwd_finalize'] = cuda_time_ms(fin, iters=10, warmup=2)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_VERSION 100  /* 0.1.0 */
+#define MS_VERSION 300  /* 0.3.0: frame executor */
 
 enum { MS_F32 = 0, MS_F64 = 1 };
 
@@ -209,16 +209,105 @@ int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile
  * (V,3) and point_heuristic (V,2) (each may be NULL).
  *
  * deterministic != 0: `moments` is (V, MS_MOMENT_ROW) INT64 (128 bytes per point, pre-zeroed) and the per-patch
- * sums are committed in 2^-32 fixed point with integer atomics, which makes the gradients bitwise reproducible
- * from run to run (float atomics add in arrival order).  Pass the same flag to both functions. */
+ * sums are committed in fixed point with integer atomics, which makes the gradients bitwise reproducible from run
+ * to run (float atomics add in arrival order).  The fixed-point unit is chosen per launch from the size of
+ * dL/dimage: ms_fixed_point_exponents turns max |grad_image| (one float in device memory, e.g. torch's amax) into
+ * the two binary exponents `fixed_exp` (device, int32[2]: sums linear in dL/dimage; the squared prune-cost sum)
+ * that both functions then read — no host round trip.  Pass the same flag and exponents to both functions.
+ * ms_raster_moments_finalize writes exact zeros for splats that can never blend (alpha or a sigma of 0). */
 #define MS_MOMENT_ROW 16
+int ms_fixed_point_exponents(const float* amax_dev, int32_t* out_exp2, void* stream);
 int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
                           const int32_t* overlap_to_point, const void* image, const void* grad_image,
                           int image_w, int image_h, const ms_raster_config* cfg, float* moments,
-                          int deterministic, int tile_row_begin, int tile_row_end, void* stream);
-int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic, int64_t n,
+                          int deterministic, const int32_t* fixed_exp, int tile_row_begin, int tile_row_end,
+                          void* stream);
+int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic,
+                               const int32_t* fixed_exp, int64_t n,
                                float* grad_points7, float* grad_features, float* point_heuristic,
                                void* stream);
+
+/* ---- frame executor --------------------------------------------------------------------------------------------
+ * One frame of render_gaussians (renderer.py:23-108) or rasterize (rasterizer/function.py:133-165) as a FIXED launch
+ * sequence without host round trips, so that a frame can be enqueued ahead of the GPU and captured in a hipGraph:
+ *
+ *   - no compaction: the reference compacts the visible gaussians (torch.nonzero + gathers and a host read of V,
+ *     perspective/projection.py:147-150).  Here all n gaussians stay in place; a culled one has depth 0, sorts last
+ *     in the depth pre-sort, overlaps no tile and gets zero gradient rows.  The tile order (tile, depth bits, point
+ *     index) is unchanged because compaction preserves the index order; overlap_to_point holds indexes into the n
+ *     input rows.
+ *   - the overlap total K stays on the device (the reference reads it back, cuda_lib/full_cumsum.cu:45-46): the
+ *     overlap list has a caller-chosen CAPACITY, the sort / range kernels read the live count from `counters`, and
+ *     when K exceeds the capacity nothing is emitted (every tile range empty, image = background) and
+ *     counters[2] = 1, so a caller that checks can re-run ms_frame_map_raster with larger buffers.
+ *
+ * ms_frame_layout reports the sizes of the four caller-owned blocks and the offsets of the arrays inside them:
+ *   keep_n / keep_k   per-gaussian / per-overlap arrays that the backward pass (and the caller) read
+ *   scratch_n / scratch_k   dead once the forward calls returned (stream order)
+ * counters (int32[8] at lay.counters in keep_n): [0] K, [1] live K (0 on overflow), [2] overflow flag.
+ *
+ * ms_frame_project_count:  camera position, projection, SH colours, depth pre-sort, overlap count, scan, K.
+ *     projected_input != 0 (2-D path, splats received for a multi-GPU strip): in->points7 / depth / colours are
+ *     used as they are and nothing is culled by depth.  k_host (pinned host int32, may be NULL) receives K;
+ *     k_event (hipEvent_t, may be NULL) is recorded right after the kernel that writes it.
+ * ms_frame_map_raster:     emission, stable sort on the tile id, tile ranges, raster forward.
+ * ms_frame_backward:       raster backward + ONE pass over the gaussians (moment rows -> 2D gradients -> projection
+ *     backward -> SH backward; csrc/gaussian_bwd.hip).  ms_frame_uses_moments(desc) != 0: the product raster
+ *     backward runs and g->moments (n, MS_MOMENT_ROW) must be zero on entry and is zero again on return;
+ *     otherwise g->grad_points7 / grad_colours are zero-initialised accumulators of ms_raster_bwd. */
+typedef struct ms_frame_desc {
+  int64_t n;                       /* gaussians = rows of every per-gaussian array */
+  int64_t k_capacity;              /* rows of the overlap list */
+  int32_t image_w, image_h;
+  int32_t dtype;                   /* MS_F32 / MS_F64 */
+  int32_t f;                       /* colour channels of the rasterizer (1..4) */
+  int32_t sh_degree;               /* -1: `feature` / `colours` are (n, f) colours; 0..3: `feature` is (n, f, (deg+1)^2) */
+  int32_t depth16;                 /* use_depth16 sort keys */
+  int32_t tile_row_begin, tile_row_end;   /* multi-GPU strip (0, INT32_MAX: whole image) */
+  int32_t projected_input;
+  int32_t reserved;
+  double near_plane, far_plane, blur_cov, clamp_margin;
+  ms_raster_config raster;
+} ms_frame_desc;
+
+typedef struct ms_frame_layout {
+  size_t keep_n_bytes, scratch_n_bytes, keep_k_bytes, scratch_k_bytes;
+  /* keep_n */
+  size_t points7, depth, colours, points7_f32, camera_position, counters, tile_ranges;
+  /* scratch_n */
+  size_t sorted_keys, order, counts, cum, ordered_points, tmp_n;
+  /* keep_k */
+  size_t overlap_to_point;
+  /* scratch_k */
+  size_t keys, values, keys_sorted, tmp_k;
+} ms_frame_layout;
+
+typedef struct ms_frame_inputs {
+  const void *position, *log_scaling, *rotation, *alpha_logit, *feature, *T_camera_world, *projection;
+  const void *points7, *depth, *colours;       /* projected_input */
+} ms_frame_inputs;
+
+typedef struct ms_frame_grads {
+  const void* image;               /* forward image (H, W, f) */
+  const void* grad_image;
+  const void *extra_points7, *extra_depth, *extra_colours;   /* dL/d(frame's own per-gaussian outputs), may be NULL */
+  void* moments;
+  int32_t deterministic, reserved;
+  const int32_t* fixed_exp;
+  void *grad_points7, *grad_colours;   /* moments path: optional stores of the summed 2D-boundary gradients */
+  void *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit, *grad_feature, *grad_camera;
+  void* point_heuristic;           /* (n, 2), written (moments path) or accumulated (zero-initialised) */
+} ms_frame_grads;
+
+int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
+int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic);
+int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
+                           int32_t* k_host, void* k_event, void* stream);
+int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
+                        void* keep_k, void* scratch_k, void* out_image, void* out_alpha, void* out_visibility,
+                        void* stream);
+int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
+                      const ms_frame_grads* g, void* stream);
 
 /* ---- optimiser step ------------------------------------------------------------
  * Moment update of the fractional (visibility-weighted) Adam (kind 0, optim/fractional_adam.py:8-86)

@@ -40,6 +40,49 @@ class RasterConfigC(ctypes.Structure):
   ]
 
 
+class FrameDescC(ctypes.Structure):
+  """``ms_frame_desc`` of include/mi355_splat.h"""
+  _fields_ = [
+    ('n', c_int64), ('k_capacity', c_int64),
+    ('image_w', c_int32), ('image_h', c_int32),
+    ('dtype', c_int32), ('f', c_int32), ('sh_degree', c_int32), ('depth16', c_int32),
+    ('tile_row_begin', c_int32), ('tile_row_end', c_int32),
+    ('projected_input', c_int32), ('reserved', c_int32),
+    ('near_plane', c_double), ('far_plane', c_double), ('blur_cov', c_double), ('clamp_margin', c_double),
+    ('raster', RasterConfigC),
+  ]
+
+
+class FrameLayoutC(ctypes.Structure):
+  """``ms_frame_layout``: byte sizes of the four blocks and offsets of the arrays inside them"""
+  _fields_ = [(name, c_size_t) for name in (
+    'keep_n_bytes', 'scratch_n_bytes', 'keep_k_bytes', 'scratch_k_bytes',
+    'points7', 'depth', 'colours', 'points7_f32', 'camera_position', 'counters', 'tile_ranges',
+    'sorted_keys', 'order', 'counts', 'cum', 'ordered_points', 'tmp_n',
+    'overlap_to_point',
+    'keys', 'values', 'keys_sorted', 'tmp_k')]
+
+
+class FrameInputsC(ctypes.Structure):
+  """``ms_frame_inputs``"""
+  _fields_ = [(name, c_void_p) for name in (
+    'position', 'log_scaling', 'rotation', 'alpha_logit', 'feature', 'T_camera_world', 'projection',
+    'points7', 'depth', 'colours')]
+
+
+class FrameGradsC(ctypes.Structure):
+  """``ms_frame_grads``"""
+  _fields_ = [
+    ('image', c_void_p), ('grad_image', c_void_p),
+    ('extra_points7', c_void_p), ('extra_depth', c_void_p), ('extra_colours', c_void_p),
+    ('moments', c_void_p), ('deterministic', c_int32), ('reserved', c_int32), ('fixed_exp', c_void_p),
+    ('grad_points7', c_void_p), ('grad_colours', c_void_p),
+    ('grad_position', c_void_p), ('grad_log_scaling', c_void_p), ('grad_rotation', c_void_p),
+    ('grad_alpha_logit', c_void_p), ('grad_feature', c_void_p), ('grad_camera', c_void_p),
+    ('point_heuristic', c_void_p),
+  ]
+
+
 # name -> (restype, argtypes); must list every function declared in include/mi355_splat.h
 SIGNATURES = {
   'ms_version': (c_int, []),
@@ -67,8 +110,14 @@ SIGNATURES = {
   'ms_strip_return_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
   'ms_fractional_update': (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
-  'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_int, c_int, c_void_p]),
-  'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_fixed_point_exponents': (c_int, [c_void_p, c_void_p, c_void_p]),
+  'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+  'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_frame_layout_query': (c_int, [POINTER(FrameDescC), POINTER(FrameLayoutC)]),
+  'ms_frame_uses_moments': (c_int, [POINTER(FrameDescC), c_int]),
+  'ms_frame_project_count': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_frame_map_raster': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC)] + [c_void_p] * 8),
+  'ms_frame_backward': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, POINTER(FrameGradsC), c_void_p]),
   'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
 }
 
@@ -149,3 +198,13 @@ def raster_config_c(config) -> RasterConfigC:
     compute_point_heuristic=int(config.compute_point_heuristic), reserved=0,
     clamp_max_alpha=config.clamp_max_alpha, alpha_threshold=config.alpha_threshold,
     saturate_threshold=config.saturate_threshold)
+
+
+def fixed_point_exponents(grad_image: torch.Tensor) -> torch.Tensor:
+  """int32[2] device tensor for the deterministic (fixed-point) raster backward: binary exponents of the units the
+  per-(patch, splat) sums are committed in, derived on the device from max |dL/dimage| (no host read)."""
+  amax = grad_image.detach().abs().amax().to(torch.float32).reshape(1)
+  out = torch.empty((2,), dtype=torch.int32, device=grad_image.device)
+  check(load().ms_fixed_point_exponents(amax.data_ptr(), out.data_ptr(), current_stream(grad_image.device)),
+        "fixed_point_exponents")
+  return out

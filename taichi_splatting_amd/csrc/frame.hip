@@ -1,0 +1,311 @@
+// frame.hip — the frame executor: one frame of the render path (project -> SH colour -> depth pre-sort -> overlap
+// count / scan / emit -> tile sort -> ranges -> raster forward; raster backward -> one per-gaussian backward pass) as
+// a FIXED sequence of launches on one stream, with no host round trip in between (include/mi355_splat.h,
+// "frame executor").  The reference orchestrates the same stages from Python with two device synchronisations per
+// frame (the visible count in torch.nonzero, perspective/projection.py:147-150; the overlap total,
+// cuda_lib/full_cumsum.cu:45-46, mapper/tile_mapper.py:183-190); here neither count ever leaves the device:
+//
+//   * visible count: not needed — nothing is compacted.  A culled gaussian keeps its row, carries depth 0, gets the
+//     sort key CULLED_DEPTH_KEY, overlaps no tile and receives zero gradients;
+//   * overlap total K: the kernels downstream of the scan read it from `counters` and run on capacity-sized grids.
+//
+// A caller may still LOOK at K (k_host / k_event) — after everything is enqueued — to grow its buffers.
+#include "common.h"
+#include "frame_internal.h"
+
+namespace ms {
+
+struct FrameGeom {
+  int w_pad, h_pad, tiles_wide, tiles_high, num_tiles, tile_bits, row_begin, row_end;
+  size_t es;            // element size of the float type
+};
+
+static FrameGeom frame_geom(const ms_frame_desc* d) {
+  FrameGeom g;
+  const int ts = d->raster.tile_size;
+  g.tiles_wide = (d->image_w + ts - 1) / ts;
+  g.tiles_high = (d->image_h + ts - 1) / ts;
+  g.w_pad = g.tiles_wide * ts;
+  g.h_pad = g.tiles_high * ts;
+  g.num_tiles = g.tiles_wide * g.tiles_high;
+  int bits = 1;
+  while ((1ll << bits) < (long long)g.num_tiles) ++bits;
+  g.tile_bits = bits;
+  g.row_begin = d->tile_row_begin < 0 ? 0 : d->tile_row_begin;
+  g.row_end = d->tile_row_end > g.tiles_high ? g.tiles_high : d->tile_row_end;
+  g.es = d->dtype == MS_F64 ? 8 : 4;
+  return g;
+}
+
+static int check_desc(const ms_frame_desc* d, const char* who) {
+  if (!d) { set_error("%s: desc is null", who); return MS_ERR_BAD_ARG; }
+  if (d->n < 0 || d->k_capacity < 0) { set_error("%s: negative size", who); return MS_ERR_BAD_ARG; }
+  if (d->n >= (1ll << 31) || d->k_capacity >= (1ll << 31)) { set_error("%s: sizes are int32 indexes (< 2^31)", who); return MS_ERR_BAD_ARG; }
+  if (d->image_w <= 0 || d->image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
+  if (d->dtype != MS_F32 && d->dtype != MS_F64) { set_error("%s: dtype must be MS_F32 or MS_F64", who); return MS_ERR_BAD_ARG; }
+  const int ts = d->raster.tile_size;
+  if (ts != 8 && ts != 16 && ts != 32) { set_error("%s: tile_size must be 8, 16 or 32 (got %d)", who, ts); return MS_ERR_UNSUPPORTED; }
+  if (d->f < 1 || d->f > 4) { set_error("%s: 1..4 colour channels (got %d)", who, d->f); return MS_ERR_UNSUPPORTED; }
+  if (d->sh_degree < -1 || d->sh_degree > 3) { set_error("%s: SH degree must be in [0, 3]", who); return MS_ERR_BAD_ARG; }
+  if (d->projected_input && d->sh_degree >= 0) { set_error("%s: projected input carries colours, not SH", who); return MS_ERR_BAD_ARG; }
+  if (d->depth16) {
+    const FrameGeom g = frame_geom(d);
+    if (g.num_tiles > 65536) { set_error("%s: use_depth16 keys hold a 16 bit tile id: too many tiles", who); return MS_ERR_BAD_ARG; }
+  }
+  return 0;
+}
+
+struct Carve {
+  size_t off = 0;
+  size_t take(size_t bytes) { const size_t o = off; off += align_up(bytes > 0 ? bytes : 1, 256); return o; }
+};
+
+static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
+  const FrameGeom g = frame_geom(d);
+  const size_t n = (size_t)d->n, k = (size_t)d->k_capacity;
+  const bool own_points = !d->projected_input;
+  Carve keep_n, scratch_n, keep_k, scratch_k;
+  L->points7 = keep_n.take(own_points ? n * 7 * g.es : 0);
+  L->depth = keep_n.take(own_points ? n * g.es : 0);
+  L->colours = keep_n.take(d->sh_degree >= 0 ? n * d->f * g.es : 0);
+  L->camera_position = keep_n.take(4 * g.es);
+  L->counters = keep_n.take(8 * sizeof(int32_t));
+  L->tile_ranges = keep_n.take((size_t)g.num_tiles * 2 * sizeof(int32_t));
+  L->keep_n_bytes = keep_n.off;
+
+  L->sorted_keys = scratch_n.take(n * 4);
+  L->order = scratch_n.take(n * 4);
+  L->counts = scratch_n.take(n * 4);
+  L->cum = scratch_n.take((n + 1) * 4);
+  L->ordered_points = scratch_n.take(n * 7 * 4);
+  L->points7_f32 = scratch_n.take(d->dtype == MS_F64 ? n * 7 * 4 : 0);
+  const size_t t1 = sort_tmp_size(d->n, 4), t2 = scan_tmp_size(d->n);
+  L->tmp_n = scratch_n.take(t1 > t2 ? t1 : t2);
+  L->scratch_n_bytes = scratch_n.off;
+
+  L->overlap_to_point = keep_k.take(k * 4);
+  L->keep_k_bytes = keep_k.off;
+
+  L->keys = scratch_k.take(k * 4);
+  L->values = scratch_k.take(k * 4);
+  L->keys_sorted = scratch_k.take(k * 4);
+  L->tmp_k = scratch_k.take(sort_tmp_size(d->k_capacity, 4));
+  L->scratch_k_bytes = scratch_k.off;
+}
+
+// K (the scan's total) -> counters[0] and the caller's pinned word
+__global__ void frame_k_kernel(const int32_t* __restrict__ total, int32_t* __restrict__ counters, int32_t* __restrict__ k_host) {
+  const int32_t k = *total;
+  counters[0] = k;
+  if (k_host) *k_host = k;
+}
+
+// live K against the capacity of this call's overlap buffers: 0 (nothing is emitted, sorted or ranged) on overflow —
+// an int32 total that wrapped negative counts as overflow
+__global__ void frame_k_limit_kernel(int32_t* __restrict__ counters, int32_t capacity) {
+  const int32_t k = counters[0];
+  const bool ok = k >= 0 && k <= capacity;
+  counters[1] = ok ? k : 0;
+  counters[2] = ok ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(256)
+f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (float)in[i];
+}
+
+static bool frame_uses_moments(const ms_frame_desc* d, int deterministic) {
+  // raster_bwd_scan.hip: float32 RGB, plain pdf; tile 32 only in the deterministic mode (the pixel-per-lane kernel
+  // is as fast there, rasterizer/function.py::_use_moments_backward)
+  if (d->dtype != MS_F32 || d->f != 3 || d->raster.antialias || !d->raster.use_alpha_blending) return false;
+  return d->raster.tile_size <= 16 || deterministic != 0;
+}
+
+}  // namespace ms
+
+using namespace ms;
+
+extern "C" int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out) {
+  int rc = check_desc(desc, "ms_frame_layout_query");
+  if (rc) return rc;
+  MS_CHECK_ARG(out != nullptr, "out is null");
+  frame_layout(desc, out);
+  return 0;
+}
+
+extern "C" int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic) {
+  return desc && frame_uses_moments(desc, deterministic) ? 1 : 0;
+}
+
+#define MS_TRY(expr)            \
+  do {                          \
+    const int rc__ = (expr);    \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
+                                      void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_project_count"));
+  MS_CHECK_ARG(in && keep_n && scratch_n, "null pointer");
+  const ms_frame_desc& d = *desc;
+  const FrameGeom g = frame_geom(desc);
+  ms_frame_layout L;
+  frame_layout(desc, &L);
+  hipStream_t s = (hipStream_t)stream;
+  char* kn = (char*)keep_n;
+  char* sn = (char*)scratch_n;
+  int32_t* counters = (int32_t*)(kn + L.counters);
+
+  if (d.n == 0) {
+    MS_CHECK_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int32_t), s));
+    if (k_host) *k_host = 0;
+    if (k_event) MS_CHECK_HIP(hipEventRecord((hipEvent_t)k_event, s));
+    return 0;
+  }
+
+  const void* points7;
+  const void* depth;
+  if (!d.projected_input) {
+    MS_CHECK_ARG(in->position && in->log_scaling && in->rotation && in->alpha_logit && in->T_camera_world && in->projection,
+                 "null gaussian / camera input");
+    MS_CHECK_ARG(in->feature != nullptr, "feature is null");
+    if (d.sh_degree >= 0)
+      MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
+    MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
+                          d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
+                          d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
+    if (d.sh_degree >= 0)
+      MS_TRY(sh_fwd_inplace_launch(in->feature, in->position, kn + L.depth, kn + L.camera_position, d.n, d.f,
+                                   d.sh_degree, kn + L.colours, d.dtype, s));
+    points7 = kn + L.points7;
+    depth = kn + L.depth;
+  } else {
+    MS_CHECK_ARG(in->points7 && in->depth && in->colours, "null projected input");
+    points7 = in->points7;
+    depth = in->depth;
+  }
+
+  // the overlap test runs in float32 like the reference (Gaussian2D from taichi_lib.f32)
+  const float* points_f32 = (const float*)points7;
+  if (d.dtype == MS_F64) {
+    float* copy = (float*)(sn + L.points7_f32);
+    f64_to_f32_kernel<<<dim3((unsigned)div_up(d.n * 7, 256)), dim3(256), 0, s>>>((const double*)points7, copy, d.n * 7);
+    points_f32 = copy;
+  }
+
+  uint32_t* sorted_keys = (uint32_t*)(sn + L.sorted_keys);
+  int32_t* order = (int32_t*)(sn + L.order);
+  int32_t* counts = (int32_t*)(sn + L.counts);
+  int32_t* cum = (int32_t*)(sn + L.cum);
+  const int cull = d.projected_input ? 0 : 1;
+  // ndc depth (renderer.py:67) is fused into the key generation when a near plane is given
+  depth_argsort_launch(depth, d.n, d.depth16, d.near_plane > 0.0 ? d.near_plane : 0.0, d.far_plane, d.dtype, cull,
+                       sorted_keys, order, sn + L.tmp_n, s);
+  tile_count_launch(points_f32, order, cull ? sorted_keys : nullptr, d.n, g.w_pad, g.h_pad, d.raster.tile_size,
+                    (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counts, (float*)(sn + L.ordered_points), s);
+  exclusive_scan_launch(counts, d.n, cum, nullptr, sn + L.tmp_n, s);
+  frame_k_kernel<<<1, 1, 0, s>>>(cum + d.n, counters, k_host);
+  MS_CHECK_LAUNCH();
+  if (k_event) MS_CHECK_HIP(hipEventRecord((hipEvent_t)k_event, s));
+  return 0;
+}
+
+extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
+                                   void* keep_k, void* scratch_k, void* out_image, void* out_alpha,
+                                   void* out_visibility, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_map_raster"));
+  MS_CHECK_ARG(in && keep_n && scratch_n && out_image && out_alpha, "null pointer");
+  const ms_frame_desc& d = *desc;
+  const FrameGeom g = frame_geom(desc);
+  ms_frame_layout L;
+  frame_layout(desc, &L);
+  hipStream_t s = (hipStream_t)stream;
+  char* kn = (char*)keep_n;
+  char* sn = (char*)scratch_n;
+  char* kk = (char*)keep_k;
+  char* sk = (char*)scratch_k;
+  int32_t* counters = (int32_t*)(kn + L.counters);
+  int32_t* ranges = (int32_t*)(kn + L.tile_ranges);
+  int32_t* o2p = (int32_t*)(kk + L.overlap_to_point);
+
+  frame_k_limit_kernel<<<1, 1, 0, s>>>(counters, (int32_t)d.k_capacity);
+  if (d.n > 0 && d.k_capacity > 0) {
+    MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
+    uint32_t* keys = (uint32_t*)(sk + L.keys);
+    int32_t* values = (int32_t*)(sk + L.values);
+    uint32_t* keys_sorted = (uint32_t*)(sk + L.keys_sorted);
+    tile_emit_ordered_launch((const float*)(sn + L.ordered_points), (const int32_t*)(sn + L.order),
+                             (const int32_t*)(sn + L.cum), d.n, g.w_pad, g.h_pad, d.raster.tile_size,
+                             (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counters + 1, keys, values, s);
+    sort_pairs_u32_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, g.tile_bits, sk + L.tmp_k, s);
+    MS_TRY(find_ranges_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s));
+  } else {
+    MS_TRY(find_ranges_dev_launch(nullptr, 0, nullptr, g.num_tiles, ranges, s));
+  }
+  MS_CHECK_LAUNCH();
+
+  const void* points7 = d.projected_input ? in->points7 : (const void*)(kn + L.points7);
+  const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
+  MS_CHECK_ARG(colours != nullptr, "colours are null");
+  return ms_raster_fwd(points7, colours, ranges, o2p, d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha,
+                       out_visibility, g.row_begin, g.row_end, d.dtype, stream);
+}
+
+extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
+                                 const ms_frame_grads* gr, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_backward"));
+  MS_CHECK_ARG(in && keep_n && gr && gr->image && gr->grad_image, "null pointer");
+  const ms_frame_desc& d = *desc;
+  const FrameGeom g = frame_geom(desc);
+  ms_frame_layout L;
+  frame_layout(desc, &L);
+  hipStream_t s = (hipStream_t)stream;
+  char* kn = (char*)keep_n;
+  char* kk = (char*)keep_k;
+  const int32_t* ranges = (const int32_t*)(kn + L.tile_ranges);
+  const int32_t* o2p = (const int32_t*)(kk + L.overlap_to_point);
+  const void* points7 = d.projected_input ? in->points7 : (const void*)(kn + L.points7);
+  const void* depth = d.projected_input ? in->depth : (const void*)(kn + L.depth);
+  const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
+  if (d.n == 0) return 0;
+
+  const bool moments = frame_uses_moments(desc, gr->deterministic);
+  if (moments) {
+    MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
+    MS_TRY(ms_raster_bwd_moments(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
+                                 (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end, stream));
+    if (d.projected_input)
+      return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
+                                            d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,
+                                            d.raster.compute_point_heuristic ? (float*)gr->point_heuristic : nullptr, s);
+  } else {
+    MS_CHECK_ARG(gr->grad_points7 || gr->grad_colours, "no gradient accumulator");
+    MS_TRY(ms_raster_bwd(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, d.f, &d.raster,
+                         gr->grad_points7, gr->grad_colours, d.raster.compute_point_heuristic ? gr->point_heuristic : nullptr,
+                         g.row_begin, g.row_end, d.dtype, stream));
+    if (d.projected_input) return 0;
+  }
+
+  GaussianBwdArgs a{};
+  a.dtype = d.dtype;
+  a.n = d.n;
+  a.position = in->position; a.log_scaling = in->log_scaling; a.rotation = in->rotation; a.alpha_logit = in->alpha_logit;
+  a.T_camera_world = in->T_camera_world; a.projection = in->projection;
+  a.image_w = d.image_w; a.image_h = d.image_h;
+  a.blur_cov = d.blur_cov; a.clamp_margin = d.clamp_margin;
+  a.depth = depth;
+  if (moments) {
+    a.moments = gr->moments; a.deterministic = gr->deterministic; a.fixed_exp = gr->fixed_exp;
+    a.store_points7 = gr->grad_points7; a.store_colours = gr->grad_colours;
+    a.point_heuristic = d.raster.compute_point_heuristic ? gr->point_heuristic : nullptr;
+  } else {
+    a.grad_points7 = gr->grad_points7; a.grad_colours = gr->grad_colours;
+  }
+  a.extra_points7 = gr->extra_points7; a.extra_depth = gr->extra_depth; a.extra_colours = gr->extra_colours;
+  a.sh_degree = d.sh_degree; a.f = d.f;
+  a.camera_position = kn + L.camera_position; a.colours = colours;
+  a.grad_position = gr->grad_position; a.grad_log_scaling = gr->grad_log_scaling; a.grad_rotation = gr->grad_rotation;
+  a.grad_alpha_logit = gr->grad_alpha_logit; a.grad_feature = gr->grad_feature; a.grad_camera = gr->grad_camera;
+  return gaussian_bwd_launch(a, s);
+}

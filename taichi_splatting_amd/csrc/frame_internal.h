@@ -1,0 +1,84 @@
+// frame_internal.h — C++ launchers shared between translation units (not part of the C-ABI): the frame executor
+// (frame.hip) strings the stages of a frame together without going back to the host, so it needs the stage
+// launchers with DEVICE-SIDE counts: grids are sized for a capacity and every kernel reads the live count from
+// memory (`*n_dev`), exits early above it, and never writes past the capacity.
+#pragma once
+#include "common.h"
+
+namespace ms {
+
+// key of a culled gaussian in the depth pre-sort (frame executor: no compaction, culled gaussians stay in place):
+// sorts behind every real depth (float bits of a non-negative depth are < 0x7f800000) and tells the overlap
+// count / emit kernels to skip the row
+constexpr uint32_t CULLED_DEPTH_KEY = 0xffffffffu;
+
+// ---- scan_sort.hip ----------------------------------------------------------------------------------------------
+size_t scan_tmp_size(int64_t n);
+size_t sort_tmp_size(int64_t n, int key_bytes);
+// exclusive scan of n int32 into out[0..n] (out[n] = total)
+void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s);
+// ms_depth_argsort with `cull`: depth <= 0 marks a culled gaussian (key CULLED_DEPTH_KEY)
+void depth_argsort_launch(const void* depth, int64_t n, int depth16, double ndc_near, double ndc_far, int dtype,
+                          int cull, uint32_t* out_sorted_keys, int32_t* out_order, char* tmp, hipStream_t s);
+// stable radix sort of u32 keys / int32 values on bits [0, end_bit): `capacity` sizes the grid and the scratch,
+// the live count is *n_dev (<= capacity)
+void sort_pairs_u32_dev_launch(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out,
+                               int64_t capacity, const int32_t* n_dev, int end_bit, char* tmp, hipStream_t s);
+// per-tile [first, last + 1) ranges of the sorted tile ids; writes every entry (zero fill included)
+int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
+                           int32_t* out_ranges, hipStream_t s);
+
+// ---- mapper.hip -------------------------------------------------------------------------------------------------
+void tile_count_launch(const float* points7, const int32_t* order, const uint32_t* cull_keys, int64_t v, int image_w,
+                       int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
+                       int32_t* out_counts, float* out_ordered, hipStream_t s);
+// key_mode 2 emission in depth order from the ordered copy; nothing is written when *k_limit_dev == 0 (overflow of
+// the caller's capacity: see frame.hip)
+void tile_emit_ordered_launch(const float* ordered_points7, const int32_t* order, const int32_t* cum, int64_t v,
+                              int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
+                              int row_end, const int32_t* k_limit_dev, uint32_t* out_keys, int32_t* out_values,
+                              hipStream_t s);
+
+// ---- sh.hip -----------------------------------------------------------------------------------------------------
+// SH colours of ALL n gaussians in place (identity index list); rows with depth[i] <= 0 (culled) get zeros and
+// their 4 F D parameter bytes are not read
+int sh_fwd_inplace_launch(const void* params, const void* positions, const void* depth, const void* cam_pos,
+                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s);
+
+// ---- raster_bwd_scan.hip ----------------------------------------------------------------------------------------
+// ms_raster_moments_finalize that also clears the rows it reads (persistent moments buffer)
+int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
+                                   int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
+                                   hipStream_t s);
+
+// ---- gaussian_bwd.hip -------------------------------------------------------------------------------------------
+// One pass over the gaussians for the whole per-gaussian backward of a frame: 2D-boundary gradients (from the raster
+// backward's moment rows, which it re-zeroes, or from gradient arrays) -> projection backward -> SH backward.
+struct GaussianBwdArgs {
+  int dtype;                 // MS_F32 / MS_F64
+  int64_t n;
+  const void *position, *log_scaling, *rotation, *alpha_logit, *T_camera_world, *projection;
+  int image_w, image_h;
+  double blur_cov, clamp_margin;
+  const void* depth;         // (n) forward depth, <= 0: culled (every gradient row of it is zero)
+  // source of d(packed 2D gaussian), d(colour): moments (n, MS_MOMENT_ROW) float (int64 when deterministic), or arrays
+  void* moments;
+  int deterministic;
+  const int32_t* fixed_exp;  // deterministic: binary exponents of the fixed-point scales (raster_bwd_scan.hip)
+  const void* grad_points7;  // (n, 7) or NULL
+  const void* grad_colours;  // (n, f) or NULL
+  // gradients arriving at the frame's own per-gaussian outputs (loss terms on gaussians2d / depth / colours)
+  const void *extra_points7, *extra_depth, *extra_colours;
+  // SH (degree >= 0): d(colour) -> d(sh params) through the clamp mask of the forward colours
+  int sh_degree, f;
+  const void *camera_position, *colours;
+  // outputs (each may be NULL)
+  void *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit;
+  void* grad_feature;        // (n, f, D) for SH, (n, f) for plain colours (moments source only)
+  void* grad_camera;         // 16 values, accumulated
+  void *store_points7, *store_colours;   // the summed 2D-boundary gradients (gaussians2d.grad / features.grad)
+  void* point_heuristic;     // (n, 2) from the moment rows
+};
+int gaussian_bwd_launch(const GaussianBwdArgs& a, hipStream_t s);
+
+}  // namespace ms

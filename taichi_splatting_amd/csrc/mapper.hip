@@ -7,6 +7,7 @@
 // formation, every product and sum rounded individually, exactly like the oracle's numpy float32.
 #pragma clang fp contract(off)
 #include "common.h"
+#include "frame_internal.h"
 
 namespace ms {
 
@@ -16,11 +17,15 @@ __device__ __forceinline__ void load_point7(const float* __restrict__ points, in
 }
 
 __global__ void __launch_bounds__(256)
-tile_count_kernel(const float* __restrict__ points, const int32_t* __restrict__ order, int64_t v, int image_w,
+tile_count_kernel(const float* __restrict__ points, const int32_t* __restrict__ order,
+                  const uint32_t* __restrict__ cull_keys, int64_t v, int image_w,
                   int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
                   int32_t* __restrict__ counts, float* __restrict__ ordered_points) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
+  // frame executor: culled gaussians stay in place and sort last (CULLED_DEPTH_KEY); they overlap nothing and their
+  // slot of the ordered copy is never read (the emit pass skips rows without overlaps)
+  if (cull_keys && cull_keys[i] == CULLED_DEPTH_KEY) { counts[i] = 0; return; }
   float g[7];
   load_point7(points, order ? (int64_t)order[i] : i, g);
   if (ordered_points) {
@@ -47,9 +52,14 @@ __global__ void __launch_bounds__(256)
 tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ depth,
                  const int32_t* __restrict__ order, const int32_t* __restrict__ cum, int64_t v,
                  int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
-                 int row_end, int points_ordered, KeyT* __restrict__ keys, int32_t* __restrict__ values) {
+                 int row_end, int points_ordered, const int32_t* __restrict__ k_limit,
+                 KeyT* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
+  // frame executor: *k_limit == 0 <=> the overlap total exceeds the capacity of keys / values: write nothing
+  if (k_limit && *k_limit == 0) return;
+  // culled gaussians of the frame executor (no entry in the ordered copy): zero overlaps, nothing to emit
+  if (k_limit && cum[i + 1] == cum[i]) return;
   const int64_t src = order ? (int64_t)order[i] : i;
   float g[7];
   load_point7(points, points_ordered ? i : src, g);
@@ -93,6 +103,22 @@ depth_keys_kernel(const T* __restrict__ depth, int64_t v, int depth16, double ne
   values[i] = (int32_t)i;
 }
 
+void tile_count_launch(const float* points7, const int32_t* order, const uint32_t* cull_keys, int64_t v, int image_w,
+                       int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
+                       int32_t* out_counts, float* out_ordered, hipStream_t s) {
+  tile_count_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, s>>>(
+      points7, order, cull_keys, v, image_w, image_h, tile_size, alpha_threshold, row_begin, row_end, out_counts, out_ordered);
+}
+
+void tile_emit_ordered_launch(const float* ordered_points7, const int32_t* order, const int32_t* cum, int64_t v,
+                              int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
+                              int row_end, const int32_t* k_limit_dev, uint32_t* out_keys, int32_t* out_values,
+                              hipStream_t s) {
+  tile_emit_kernel<uint32_t, 2><<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, s>>>(
+      ordered_points7, nullptr, order, cum, v, image_w, image_h, tile_size, alpha_threshold, row_begin, row_end, 1,
+      k_limit_dev, out_keys, out_values);
+}
+
 }  // namespace ms
 
 using namespace ms;
@@ -121,7 +147,7 @@ extern "C" int ms_tile_count(const float* points7, const int32_t* order, int64_t
   if (v == 0) return 0;
   MS_CHECK_ARG(points7 && out_counts, "null pointer");
   tile_count_kernel<<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      points7, order, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts, out_ordered_points7);
+      points7, order, nullptr, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, out_counts, out_ordered_points7);
   MS_CHECK_LAUNCH();
   return 0;
 }
@@ -143,7 +169,7 @@ extern "C" int ms_tile_emit(const float* points7, const float* depth, const int3
   MS_CHECK_ARG(key_mode == 2 || depth, "depth is null");
   const dim3 block(256), grid((unsigned)div_up(v, 256));
   hipStream_t s = (hipStream_t)stream;
-#define MS_EMIT(KeyT, MODE) tile_emit_kernel<KeyT, MODE><<<grid, block, 0, s>>>(points7, depth, order, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, points_are_ordered, (KeyT*)out_keys, out_values)
+#define MS_EMIT(KeyT, MODE) tile_emit_kernel<KeyT, MODE><<<grid, block, 0, s>>>(points7, depth, order, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end, points_are_ordered, nullptr, (KeyT*)out_keys, out_values)
   if (key_mode == 0) MS_EMIT(uint64_t, 0);
   else if (key_mode == 1) MS_EMIT(uint32_t, 1);
   else MS_EMIT(uint32_t, 2);

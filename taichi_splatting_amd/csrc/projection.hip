@@ -45,7 +45,7 @@ project_fwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
   o[4] = st.sigma[0]; o[5] = st.sigma[1];
   o[6] = st.alpha;
   out_depth[i] = in_view ? st.pc[2] : T(0);
-  out_flag[i] = in_view ? 1 : 0;
+  if (out_flag) out_flag[i] = in_view ? 1 : 0;
 }
 
 template <typename T>
@@ -138,7 +138,7 @@ extern "C" int ms_project_fwd(const void* position, const void* log_scaling, con
   if (n == 0) return 0;
   MS_CHECK_ARG(position && log_scaling && rotation && alpha_logit && T_camera_world && projection,
                "null input");
-  MS_CHECK_ARG(out_points7 && out_depth && out_flag, "null output");
+  MS_CHECK_ARG(out_points7 && out_depth, "null output");   // out_flag may be NULL (depth > 0 <=> in view)
   const dim3 block(256), grid((unsigned)div_up(n, 256));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MS_F32) {

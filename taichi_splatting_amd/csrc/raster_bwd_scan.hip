@@ -33,6 +33,7 @@
 // VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~46 instructions / (lanes filled) ~= 16 wave
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
 #include "raster_common.h"
+#include "frame_internal.h"
 
 // Development builds (tools/abl): -DMS_SCAN_STATS counts chunks / filled lanes / executed pixel steps into
 // g_scan_stats (read with ms_debug_scan_stats); -DMS_SCAN_ABLATE=1 skips the blend phase, =2 the cull + blend.
@@ -50,11 +51,22 @@ __device__ unsigned long long g_scan_stats[12];
 #endif
 
 constexpr int MOMENT_ROW = MS_MOMENT_ROW;     // floats per point in the moments buffer (64 B, line aligned)
-// Deterministic mode: the per-(patch, splat) sums are committed as 64-bit fixed-point integers (2^-32 units,
-// |sum| < 2^31) with INTEGER atomics.  Integer addition is associative, so the accumulated row does not depend on
-// the order in which the patches of different tiles reach memory and the gradients are bitwise reproducible;
-// everything before the commit (scans, per-lane sums, per-wave LDS rows) already runs in program order.
-constexpr float FIXED_POINT_SCALE = 4294967296.0f;
+// Deterministic mode: the per-(patch, splat) sums are committed as 64-bit fixed-point integers with INTEGER atomics.
+// Integer addition is associative, so the accumulated row does not depend on the order in which the patches of
+// different tiles reach memory and the gradients are bitwise reproducible; everything before the commit (scans,
+// per-lane sums, per-wave LDS rows) already runs in program order.  The unit is 2^-e with e chosen PER LAUNCH from
+// max |dL/dimage| (ms_fixed_point_exponents; a fixed 2^-32 kept a few bits only of the gradients of a mean-reduced
+// loss, dL/dC ~ 1e-7, and rounded the squared heuristic term to 0): e_main for the nine sums that are linear in
+// dL/dimage and for split_score, e_h0 for prune_cost's sum of (dL/dalpha)^2.
+constexpr int FIXED_POINT_BITS = 36;      // a commit of magnitude max|dL/dimage| is worth 2^36 units
+__global__ void fixed_point_exponents_kernel(const float* __restrict__ amax, int32_t* __restrict__ out) {
+  const float m = *amax;
+  int e = 0;
+  if (m > 0.0f && m < __builtin_inff()) (void)frexpf(m, &e);        // m = f * 2^e, f in [0.5, 1)
+  int e_main = FIXED_POINT_BITS - e, e_h0 = FIXED_POINT_BITS - 2 * e;
+  out[0] = e_main < -100 ? -100 : (e_main > 100 ? 100 : e_main);
+  out[1] = e_h0 < -100 ? -100 : (e_h0 > 100 ? 100 : e_h0);
+}
 
 // Inclusive prefix product / sum over the 64 lanes: row_shr:1,2,4,8 build the 16-lane row prefixes, row_bcast:15
 // (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the row totals — six DPP instructions.  Lanes without a source
@@ -138,7 +150,7 @@ __global__ void __launch_bounds__(TS * TS)
 raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
                        const float* __restrict__ image, const float* __restrict__ grad_image,
-                       FastParams rp, float* __restrict__ moments) {
+                       FastParams rp, float* __restrict__ moments, const int32_t* __restrict__ fixed_exp) {
   constexpr int THREADS = TS * TS, WAVES = THREADS / 64, WAVES_WIDE = TS / 8;
   // Splats staged per batch (shared by the tile's waves).  A tile's list is cut into EQUAL batches of about
   // BATCH_TARGET (see the batch loop): with fixed 256-splat batches config D's ~779 splats per tile end in an
@@ -197,6 +209,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     s_rg[wave][lane] = RG;
   }
   const bool last_lane = lane == 63;
+  float fixed_main = 0.f, fixed_h0 = 0.f;
+  if (rp.deterministic) { fixed_main = ldexpf(1.0f, fixed_exp[0]); fixed_h0 = ldexpf(1.0f, fixed_exp[1]); }
   const float oms = rp.one_minus_saturate;
   const uint32_t oms_bits = __float_as_uint(oms);     // T >= 0: the float order is the order of the bit patterns
 
@@ -491,7 +505,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           if (v != 0.0f) {
             const size_t word = (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k;
             if (rp.deterministic)
-              __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word, (long long)llrintf(v * FIXED_POINT_SCALE),
+              __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
+                                     (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else
               atomic_add_noret(moments + word, v);
@@ -518,28 +533,37 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 //   d mean  = M^T (Sx, Sy)                                  d sigma = (Sxx / sx, Syy / sy)
 //   d axis  = sum q (X/sx (-d) + Y/sy perp(d)),  d = M^-1 (X, Y)     d alpha = S / alpha      (generic.py:321-336)
 // The kernel stores the moments of (X', Y') = s (X, Y), s = sqrt(log2(e) / 2).
-template <bool HEUR, bool FIXED>
+// REZERO (frame executor): the rows are cleared as they are read, so a persistent moments buffer needs no fill pass.
+template <bool HEUR, bool FIXED, bool REZERO = false>
 __global__ void __launch_bounds__(256)
-raster_moments_finalize_kernel(const float* __restrict__ points, const float* __restrict__ moments, int64_t n,
+raster_moments_finalize_kernel(const float* __restrict__ points, float* __restrict__ moments, int64_t n,
                                float* __restrict__ grad_points, float* __restrict__ grad_feats,
-                               float* __restrict__ heuristic) {
+                               float* __restrict__ heuristic, const int32_t* __restrict__ fixed_exp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 r0, r1, r2;
   if (FIXED) {       // deterministic mode: rows of 64-bit fixed-point integers
-    const long long* row = reinterpret_cast<const long long*>(moments) + i * MOMENT_ROW;
+    long long* row = reinterpret_cast<long long*>(moments) + i * MOMENT_ROW;
+    const int e_main = fixed_exp[0], e_h0 = fixed_exp[1];
     float v[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) v[k] = (float)((double)row[k] * (1.0 / (double)FIXED_POINT_SCALE));
+    for (int k = 0; k < 12; ++k) {
+      v[k] = (float)ldexp((double)row[k], k == 9 ? -e_h0 : -e_main);
+      if (REZERO) row[k] = 0;
+    }
     r0 = make_float4(v[0], v[1], v[2], v[3]); r1 = make_float4(v[4], v[5], v[6], v[7]); r2 = make_float4(v[8], v[9], v[10], v[11]);
   } else {
-    const float4* row = reinterpret_cast<const float4*>(moments + i * MOMENT_ROW);
+    float4* row = reinterpret_cast<float4*>(moments + i * MOMENT_ROW);
     r0 = row[0]; r1 = row[1]; r2 = row[2];
+    if (REZERO) { const float4 z = make_float4(0.f, 0.f, 0.f, 0.f); row[0] = z; row[1] = z; row[2] = z; }
   }
   if (grad_points) {
     const float* g = points + i * 7;
     const float ax = g[2], ay = g[3], sx = g[4], sy = g[5], alpha = g[6];
-    const float isx = 1.0f / sx, isy = 1.0f / sy;
+    // a splat the rasterizer can never blend (alpha or a sigma of 0: masked / underflowed parameters of a direct
+    // rasterize() caller) has an all-zero row; its gradient is exactly zero like the atomic path's (0 / 0 otherwise)
+    const bool dead = !(alpha > 0.0f) || !(sx > 0.0f) || !(sy > 0.0f);
+    const float isx = dead ? 0.0f : 1.0f / sx, isy = dead ? 0.0f : 1.0f / sy;
     const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
     constexpr float IS = 1.0f / EXP2_BASIS_SCALE, IS2 = IS * IS;
     const float S = r0.x, Sx = r0.y * IS, Sy = r0.z * IS, Sxx = r0.w * IS2, Sxy = r1.x * IS2, Syy = r1.y * IS2;
@@ -552,7 +576,7 @@ raster_moments_finalize_kernel(const float* __restrict__ points, const float* __
     o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
     o[4] = isx * Sxx;
     o[5] = isy * Syy;
-    o[6] = S / alpha;
+    o[6] = dead ? 0.0f : S / alpha;
   }
   if (HEUR && heuristic) {                       // backward.py:190-194: sum (alpha d_alpha)^2, sum |d mean|_1
     const float alpha = points[i * 7 + 6];
@@ -572,8 +596,9 @@ using namespace ms;
 static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
-                                float* moments, int deterministic, int tile_row_begin, int tile_row_end, hipStream_t s,
-                                const char* who) {
+                                float* moments, int deterministic, const int32_t* fixed_exp, int tile_row_begin,
+                                int tile_row_end, hipStream_t s, const char* who) {
+  if (deterministic && !fixed_exp) { set_error("%s: deterministic commits need fixed_exp (ms_fixed_point_exponents)", who); return MS_ERR_BAD_ARG; }
   if (image_w <= 0 || image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
   if (!cfg->use_alpha_blending) {
     set_error("%s: backward requires use_alpha_blending (reference: tests/test_rasterizer.py:92-94)", who);
@@ -596,7 +621,7 @@ static int launch_scan_backward(const float* points7, const float* features,
   rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
 #define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT>                                           \
       <<<dim3(xcd_grid<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, SPLIT * SPLIT)), dim3(TS * TS), 0, s>>>(              \
-          points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments)
+          points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp)
 #define MS_GO_TILE(TS, SPLIT)                                                                                   \
   do { if (hf) MS_GO(TS, true, SPLIT); else MS_GO(TS, false, SPLIT); } while (0)
   const bool hf = cfg->compute_point_heuristic;
@@ -614,11 +639,20 @@ static int launch_scan_backward(const float* points7, const float* features,
 extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, const int32_t* tile_ranges,
                                      const int32_t* overlap_to_point, const void* image, const void* grad_image,
                                      int image_w, int image_h, const ms_raster_config* cfg, float* moments,
-                                     int deterministic, int tile_row_begin, int tile_row_end, void* stream) {
+                                     int deterministic, const int32_t* fixed_exp, int tile_row_begin,
+                                     int tile_row_end, void* stream) {
   MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments, "null pointer");
   return launch_scan_backward((const float*)points7, (const float*)features, tile_ranges, overlap_to_point,
                               (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
-                              deterministic, tile_row_begin, tile_row_end, (hipStream_t)stream, "ms_raster_bwd_moments");
+                              deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
+                              "ms_raster_bwd_moments");
+}
+
+extern "C" int ms_fixed_point_exponents(const float* amax_dev, int32_t* out_exp2, void* stream) {
+  MS_CHECK_ARG(amax_dev && out_exp2, "null pointer");
+  fixed_point_exponents_kernel<<<1, 1, 0, (hipStream_t)stream>>>(amax_dev, out_exp2);
+  MS_CHECK_LAUNCH();
+  return 0;
 }
 
 #if MS_SCAN_STATS
@@ -629,20 +663,39 @@ extern "C" int ms_debug_scan_stats(unsigned long long* out10, int reset) {
 }
 #endif
 
-extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic, int64_t n,
+extern "C" int ms_raster_moments_finalize(const void* points7, const float* moments, int deterministic,
+                                          const int32_t* fixed_exp, int64_t n,
                                           float* grad_points7, float* grad_features, float* point_heuristic,
                                           void* stream) {
   MS_CHECK_ARG(n >= 0, "negative size");
+  MS_CHECK_ARG(!deterministic || fixed_exp, "deterministic rows need fixed_exp");
   if (n == 0) return 0;
   MS_CHECK_ARG(points7 && moments, "null pointer");
   if (!grad_points7 && !grad_features && !point_heuristic) return 0;
   const dim3 grid((unsigned)div_up(n, 256));
   hipStream_t s = (hipStream_t)stream;
 #define MS_GO(HEUR, FIXED) raster_moments_finalize_kernel<HEUR, FIXED><<<grid, 256, 0, s>>>(            \
-      (const float*)points7, moments, n, grad_points7, grad_features, point_heuristic)
+      (const float*)points7, const_cast<float*>(moments), n, grad_points7, grad_features, point_heuristic, fixed_exp)
   if (point_heuristic) { if (deterministic) MS_GO(true, true); else MS_GO(true, false); }
   else { if (deterministic) MS_GO(false, true); else MS_GO(false, false); }
 #undef MS_GO
   MS_CHECK_LAUNCH();
   return 0;
 }
+
+// frame executor (frame_internal.h): finalize + re-zero of the rows it read
+namespace ms {
+int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
+                                   int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
+                                   hipStream_t s) {
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)div_up(n, 256));
+#define MS_GO(HEUR, FIXED) raster_moments_finalize_kernel<HEUR, FIXED, true><<<grid, 256, 0, s>>>(      \
+      points7, moments, n, grad_points7, grad_features, point_heuristic, fixed_exp)
+  if (point_heuristic) { if (deterministic) MS_GO(true, true); else MS_GO(true, false); }
+  else { if (deterministic) MS_GO(false, true); else MS_GO(false, false); }
+#undef MS_GO
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+}  // namespace ms

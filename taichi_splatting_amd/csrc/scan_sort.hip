@@ -11,6 +11,7 @@
 // wave-major, round-major, lane-minor, so loads are fully coalesced and stability only needs
 // (earlier waves) + (earlier rounds of this wave) + (lower lanes of this round).
 #include "common.h"
+#include "frame_internal.h"
 
 namespace ms {
 
@@ -208,15 +209,21 @@ template <typename T> struct DepthPairs {
   const T* depth;
   int depth16;
   double near_plane, far_plane;
-  __device__ __forceinline__ uint32_t key(int64_t i) const { return depth_sort_key(depth[i], depth16, near_plane, far_plane); }
+  int cull;          // frame executor: depth <= 0 marks a culled gaussian, which sorts last and is skipped downstream
+  __device__ __forceinline__ uint32_t key(int64_t i) const {
+    const T d = depth[i];
+    if (cull && !(d > T(0))) return CULLED_DEPTH_KEY;
+    return depth_sort_key(d, depth16, near_plane, far_plane);
+  }
   __device__ __forceinline__ int32_t val(int64_t i) const { return (int32_t)i; }
 };
 
 template <typename KeyT, typename Source>
 __global__ void __launch_bounds__(RS_THREADS)
-radix_upsweep_kernel(const Source src, int64_t n, int shift, unsigned mask,
+radix_upsweep_kernel(const Source src, int64_t n, const int32_t* __restrict__ n_dev, int shift, unsigned mask,
                      int32_t* __restrict__ hist, int64_t num_blocks) {
   __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
+  if (n_dev) n = *n_dev;        // live count on the device; the grid covers the capacity (idle blocks write zeros)
   for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -386,10 +393,15 @@ __device__ __forceinline__ void downsweep_block(DownsweepShared<KeyT>& sh, const
 template <typename KeyT, typename Source>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_downsweep_kernel(const Source src,
-                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n, int shift,
+                       KeyT* __restrict__ keys_out, int32_t* __restrict__ vals_out, int64_t n,
+                       const int32_t* __restrict__ n_dev, int shift,
                        unsigned mask, const int32_t* __restrict__ hist_scanned,
                        const int32_t* __restrict__ digit_totals, int64_t num_blocks) {
   __shared__ DownsweepShared<KeyT> sh;
+  if (n_dev) {
+    n = *n_dev;
+    if ((int64_t)blockIdx.x * RS_TILE >= n) return;
+  }
   if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n)
     downsweep_block<KeyT, true>(sh, src, keys_out, vals_out, n, shift, mask, hist_scanned, digit_totals, num_blocks);
   else
@@ -424,7 +436,7 @@ static SortTmp sort_tmp_layout(int64_t n, int key_bytes) {
 // ping-pong buffers.
 template <typename KeyT, typename First>
 static int radix_sort_passes(const First first, KeyT* keys_out, int32_t* vals_out, int64_t n, int begin_bit, int end_bit,
-                             char* tmp, hipStream_t s) {
+                             char* tmp, hipStream_t s, const int32_t* n_dev = nullptr) {
   const int64_t blocks = div_up(n, RS_TILE);
   const SortTmp lay = sort_tmp_layout(n, sizeof(KeyT));
   int32_t* hist = (int32_t*)(tmp + lay.hist_off);
@@ -441,11 +453,11 @@ static int radix_sort_passes(const First first, KeyT* keys_out, int32_t* vals_ou
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     KeyT* dst_k = to_out ? keys_out : keys_alt;
     int32_t* dst_v = to_out ? vals_out : vals_alt;
-    if (p == 0) radix_upsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, n, shift, mask, hist, blocks);
-    else radix_upsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, n, shift, mask, hist, blocks);
+    if (p == 0) radix_upsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, n, n_dev, shift, mask, hist, blocks);
+    else radix_upsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, n, n_dev, shift, mask, hist, blocks);
     radix_row_scan_kernel<<<dim3(RS_RADIX), dim3(SCAN_THREADS), 0, s>>>(hist, blocks, digit_totals);
-    if (p == 0) radix_downsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
-    else radix_downsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, dst_k, dst_v, n, shift, mask, hist, digit_totals, blocks);
+    if (p == 0) radix_downsweep_kernel<KeyT, First><<<grid, block, 0, s>>>(first, dst_k, dst_v, n, n_dev, shift, mask, hist, digit_totals, blocks);
+    else radix_downsweep_kernel<KeyT, PlainPairs<KeyT>><<<grid, block, 0, s>>>(src, dst_k, dst_v, n, n_dev, shift, mask, hist, digit_totals, blocks);
     src = PlainPairs<KeyT>{dst_k, dst_v};
   }
   return 0;
@@ -484,9 +496,10 @@ segmented_rank_sort_kernel(const int32_t* __restrict__ keys_in, const int32_t* _
 
 template <typename KeyT>
 __global__ void __launch_bounds__(256)
-find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, int shift, int64_t num_tiles,
-                   int32_t* __restrict__ ranges) {
+find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, const int32_t* __restrict__ k_dev, int shift,
+                   int64_t num_tiles, int32_t* __restrict__ ranges) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k_dev) k = *k_dev;
   if (i >= k) return;
   const int64_t tile = (int64_t)(keys[i] >> shift);
   const int64_t next = (i + 1 < k) ? (int64_t)(keys[i + 1] >> shift) : -1;
@@ -495,6 +508,36 @@ find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, int shift, int64_t 
     if (tile < num_tiles) ranges[tile * 2 + 1] = (int32_t)(i + 1);
     if (next >= 0 && next < num_tiles) ranges[next * 2 + 0] = (int32_t)(i + 1);
   }
+}
+
+// ---- launchers for the frame executor (frame_internal.h) ----------------------------------------------------------
+size_t scan_tmp_size(int64_t n) { return scan_tmp_bytes(n); }
+size_t sort_tmp_size(int64_t n, int key_bytes) { return sort_tmp_layout(n, key_bytes).total; }
+
+void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s) {
+  exclusive_scan_i32(in, n, out, total_host, tmp, s);
+}
+
+void depth_argsort_launch(const void* depth, int64_t n, int depth16, double ndc_near, double ndc_far, int dtype,
+                          int cull, uint32_t* out_sorted_keys, int32_t* out_order, char* tmp, hipStream_t s) {
+  const int end_bit = depth16 ? 16 : 32;
+  if (dtype == MS_F32)
+    radix_sort_passes<uint32_t>(DepthPairs<float>{(const float*)depth, depth16, ndc_near, ndc_far, cull}, out_sorted_keys, out_order, n, 0, end_bit, tmp, s);
+  else
+    radix_sort_passes<uint32_t>(DepthPairs<double>{(const double*)depth, depth16, ndc_near, ndc_far, cull}, out_sorted_keys, out_order, n, 0, end_bit, tmp, s);
+}
+
+void sort_pairs_u32_dev_launch(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out,
+                               int64_t capacity, const int32_t* n_dev, int end_bit, char* tmp, hipStream_t s) {
+  radix_sort_passes<uint32_t>(PlainPairs<uint32_t>{keys_in, vals_in}, keys_out, vals_out, capacity, 0, end_bit, tmp, s, n_dev);
+}
+
+int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
+                           int32_t* out_ranges, hipStream_t s) {
+  if (num_tiles > 0) MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), s));
+  if (capacity > 0)
+    find_ranges_kernel<uint32_t><<<dim3((unsigned)div_up(capacity, 256)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, 0, num_tiles, out_ranges);
+  return 0;
 }
 
 }  // namespace ms
@@ -553,9 +596,9 @@ extern "C" int ms_depth_argsort(const void* depth, int64_t v, int depth16, doubl
   MS_CHECK_ARG(depth && out_sorted_keys && out_order, "null pointer");
   const int end_bit = depth16 ? 16 : 32;
   if (dtype == MS_F32)
-    radix_sort_passes<uint32_t>(DepthPairs<float>{(const float*)depth, depth16, ndc_near, ndc_far}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
+    radix_sort_passes<uint32_t>(DepthPairs<float>{(const float*)depth, depth16, ndc_near, ndc_far, 0}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
   else
-    radix_sort_passes<uint32_t>(DepthPairs<double>{(const double*)depth, depth16, ndc_near, ndc_far}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
+    radix_sort_passes<uint32_t>(DepthPairs<double>{(const double*)depth, depth16, ndc_near, ndc_far, 0}, out_sorted_keys, out_order, v, 0, end_bit, (char*)tmp, (hipStream_t)stream);
   MS_CHECK_LAUNCH();
   return 0;
 }
@@ -586,9 +629,9 @@ extern "C" int ms_find_ranges(const void* sorted_keys, int64_t k, int key_bytes,
   MS_CHECK_ARG(sorted_keys != nullptr, "sorted_keys is null");
   const dim3 block(256), grid((unsigned)div_up(k, 256));
   if (key_bytes == 4)
-    find_ranges_kernel<uint32_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint32_t*)sorted_keys, k, tile_shift, num_tiles, out_ranges);
+    find_ranges_kernel<uint32_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint32_t*)sorted_keys, k, nullptr, tile_shift, num_tiles, out_ranges);
   else
-    find_ranges_kernel<uint64_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint64_t*)sorted_keys, k, tile_shift, num_tiles, out_ranges);
+    find_ranges_kernel<uint64_t><<<grid, block, 0, (hipStream_t)stream>>>((const uint64_t*)sorted_keys, k, nullptr, tile_shift, num_tiles, out_ranges);
   MS_CHECK_LAUNCH();
   return 0;
 }

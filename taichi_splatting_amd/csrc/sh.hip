@@ -3,6 +3,7 @@
 // One thread per visible gaussian; params rows are (F, D) contiguous (D = (deg+1)^2), i.e. 192 B
 // per gaussian for RGB degree 3: a pure HBM stream, gathered through the int64 index list.
 #include "common.h"
+#include "frame_internal.h"
 
 namespace ms {
 
@@ -12,11 +13,17 @@ template <typename T, int DEG>
 __global__ void __launch_bounds__(256)
 sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
               const int64_t* __restrict__ indexes, const T* __restrict__ cam_pos, int64_t v, int f,
-              T* __restrict__ out) {
+              T* __restrict__ out, const T* __restrict__ cull_depth = nullptr) {
   constexpr int D = (DEG + 1) * (DEG + 1);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
-  const int64_t idx = indexes[i];
+  // frame executor: indexes == NULL is the identity list over ALL gaussians; culled ones (depth <= 0) get zeros
+  // without touching their parameter row
+  if (cull_depth && !(cull_depth[i] > T(0))) {
+    for (int c = 0; c < f; ++c) out[i * f + c] = T(0);
+    return;
+  }
+  const int64_t idx = indexes ? indexes[i] : i;
 
   const T dx = positions[idx * 3 + 0] - cam_pos[0];
   const T dy = positions[idx * 3 + 1] - cam_pos[1];
@@ -215,6 +222,29 @@ static int launch_sh_bwd(const void* params, const void* positions, const int64_
     default: MS_SH_BWD(3); break;
   }
 #undef MS_SH_BWD
+  return 0;
+}
+
+template <typename T>
+static void launch_sh_fwd_inplace(const void* params, const void* positions, const void* depth, const void* cam,
+                                  int64_t n, int f, int degree, void* out, hipStream_t s) {
+  const dim3 block(256), grid((unsigned)div_up(n, 256));
+#define MS_SH_FWD(DEG) \
+  sh_fwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, nullptr, (const T*)cam, n, f, (T*)out, (const T*)depth)
+  switch (degree) {
+    case 0: MS_SH_FWD(0); break;
+    case 1: MS_SH_FWD(1); break;
+    case 2: MS_SH_FWD(2); break;
+    default: MS_SH_FWD(3); break;
+  }
+#undef MS_SH_FWD
+}
+
+int sh_fwd_inplace_launch(const void* params, const void* positions, const void* depth, const void* cam_pos,
+                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s) {
+  if (n == 0) return 0;
+  if (dtype == MS_F32) launch_sh_fwd_inplace<float>(params, positions, depth, cam_pos, n, f, degree, out, s);
+  else launch_sh_fwd_inplace<double>(params, positions, depth, cam_pos, n, f, degree, out, s);
   return 0;
 }
 

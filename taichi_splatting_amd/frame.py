@@ -1,0 +1,520 @@
+"""A whole frame as ONE autograd node on a fixed launch sequence (csrc/frame.hip, include/mi355_splat.h
+"frame executor").
+
+``render_gaussians`` (reference ``renderer.py:23-108``) runs through here: projection, SH colour, depth pre-sort,
+overlap count / scan / emission, tile sort, ranges and the raster forward are enqueued by two C calls, the backward
+pass by one (raster backward + ONE pass over the gaussians).  Differences to the reference's orchestration, none of
+them visible in results:
+
+* nothing is compacted and the visible count V is never read back: culled gaussians keep their row (depth 0, no
+  overlaps, zero gradients).  The compacted ``(V, ...)`` arrays of ``Rendering.points`` are made when a caller
+  touches them (``LazyPoints``) — that access is the only place a host synchronisation on V remains;
+* the overlap total K stays on the device.  The overlap buffers have a capacity remembered per scene shape; in eager
+  mode the host looks at K (pinned word + event) only AFTER the whole forward is enqueued, so the GPU never waits for
+  it, and re-runs the emission with larger buffers in the rare case the capacity was exceeded.  Under HIP-graph
+  capture (``FrameGraph`` / ``torch.cuda.graph``) nothing is read back: the capacity is fixed at capture time and an
+  overflow shows in ``frame_status``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, replace
+import os
+from typing import Optional, Tuple
+import weakref
+
+import torch
+
+from . import _lib
+from .data_types import RasterConfig
+
+# MS_FRAME=legacy: render_gaussians composes the modular operators (project_to_image, evaluate_sh_at, map_to_tiles,
+# rasterize_with_tiles) as in rounds 1-2 — kept for A/B measurements and as the cross-check of the frame path
+USE_FRAME = os.environ.get('MS_FRAME', 'frame') != 'legacy'
+
+K_SLACK = 1.25            # capacity = K_SLACK x the largest overlap total seen for this scene shape
+K_GRANULE = 1 << 16
+
+_k_capacity = {}          # scene-shape key -> overlap-list capacity
+_k_host = {}              # device index -> (pinned int32[1], torch.cuda.Event)
+_moments = {}             # (device index, n, deterministic) -> persistent accumulator rows, zero between frames
+_identity = {}            # (device index, n) -> arange(n) int64
+
+host_syncs = 0            # forward-pass waits on the overlap total (non-stalling: the frame is already enqueued)
+point_syncs = 0           # LazyPoints materialisations (host read of the visible count)
+
+
+@dataclass(frozen=True)
+class FrameOptions:
+  image_size: Tuple[int, int]
+  depth_range: Tuple[float, float]
+  config: RasterConfig
+  use_sh: bool
+  use_depth16: bool = False
+  tile_rows: Optional[Tuple[int, int]] = None
+  crop_to_rows: bool = False
+  render_median_depth: bool = False
+
+
+def frame_supported(feature: torch.Tensor, config: RasterConfig, use_sh: bool) -> bool:
+  """The executor instantiates 1..4 colour channels (csrc/raster.hip); wider feature vectors take the modular
+  operators, which chunk the channels."""
+  f = feature.shape[1]
+  return 1 <= f <= 4 and feature.is_cuda
+
+
+def set_overlap_capacity(n: int, image_size, config: RasterConfig, capacity: int, device=None, tile_rows=None,
+                         use_depth16: bool = False):
+  """Fix the overlap-list capacity for a scene shape (needed before capturing a frame in a HIP graph when no eager
+  frame of that shape has run yet)."""
+  dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+  _k_capacity[_shape_key(dev, n, image_size, config, tile_rows, use_depth16)] = _round_capacity(capacity)
+
+
+def _shape_key(device, n, image_size, config, tile_rows, depth16):
+  return (device.index, int(n), int(image_size[0]), int(image_size[1]), config.tile_size,
+          None if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1])), bool(depth16))
+
+
+def _round_capacity(k: int) -> int:
+  k = max(int(k), 1)
+  return min((k + K_GRANULE - 1) // K_GRANULE * K_GRANULE, (1 << 31) - 1)
+
+
+def _pinned_k(device):
+  entry = _k_host.get(device.index)
+  if entry is None:
+    word = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    entry = _k_host[device.index] = (word, torch.cuda.Event())
+  return entry
+
+
+def identity_indexes(n: int, device) -> torch.Tensor:
+  """arange(n) int64, shared: callers treat index lists as read-only.  Built outside inference mode so that a first
+  use under ``torch.inference_mode()`` (evaluation render) does not poison later training frames."""
+  key = (device.index, int(n))
+  cached = _identity.get(key)
+  if cached is None:
+    _identity.clear()
+    with torch.inference_mode(False):
+      cached = _identity[key] = torch.arange(n, dtype=torch.int64, device=device)
+  return cached
+
+
+def _moments_buffer(device, n: int, deterministic: bool) -> torch.Tensor:
+  """Persistent (n, MOMENT_ROW) accumulator of the raster backward: zero on entry of every backward pass, and zero
+  again when it returns (the per-gaussian pass clears the rows it reads) — no 64 B-per-gaussian fill per frame."""
+  key = (device.index, int(n), bool(deterministic))
+  buf = _moments.get(key)
+  if buf is None:
+    for k in [k for k in _moments if k[0] == device.index and k[2] == bool(deterministic)]:
+      del _moments[k]                       # one scene size at a time per device
+    buf = _moments[key] = torch.zeros((max(n, 1), _lib.MOMENT_ROW), dtype=torch.int64 if deterministic else torch.float32,
+                                      device=device)
+  return buf
+
+
+class FrameState:
+  """What one frame keeps between its forward pass, its backward pass and the lazily built ``points``."""
+
+  def __init__(self):
+    self.desc = None
+    self.layout = None
+    self.inputs = None
+    self.keep_n = None
+    self.keep_k = None
+    self.k = None                 # overlap total (eager mode), None under graph capture
+    self.capacity = 0
+    self.children = []            # (weakref to a tensor handed out, index list or None, 'points7' | 'colours')
+    self.y0 = 0
+
+  def counters(self) -> torch.Tensor:
+    return self.keep_n[self.layout.counters:self.layout.counters + 32].view(torch.int32)
+
+  def overlap_to_point(self) -> torch.Tensor:
+    off = self.layout.overlap_to_point
+    return self.keep_k[off:off + 4 * self.capacity].view(torch.int32)
+
+  def tile_ranges(self) -> torch.Tensor:
+    off = self.layout.tile_ranges
+    ts = self.desc.raster.tile_size
+    th, tw = (self.desc.image_h + ts - 1) // ts, (self.desc.image_w + ts - 1) // ts
+    return self.keep_n[off:off + 8 * th * tw].view(torch.int32).view(th, tw, 2)
+
+  def register(self, tensor: torch.Tensor, idx, kind: str):
+    self.children.append((weakref.ref(tensor), idx, kind))
+
+  def retained(self):
+    out = []
+    for ref, idx, kind in self.children:
+      t = ref()
+      if t is not None and t.requires_grad and t.retains_grad:
+        out.append((t, idx, kind))
+    return out
+
+
+def _view(block: torch.Tensor, offset: int, dtype, shape):
+  count = 1
+  for s in shape:
+    count *= s
+  nbytes = count * torch.empty((), dtype=dtype).element_size()
+  return block[offset:offset + nbytes].view(dtype).view(*shape)
+
+
+def _strip_pixels(rows, tile_size, h):
+  return min(rows[0] * tile_size, h), min(rows[1] * tile_size, h)
+
+
+class _FrameFunction(torch.autograd.Function):
+  """project -> SH -> map -> rasterize as one node (reference: perspective/projection.py:123-188,
+  indexed_spherical_harmonics.py:138-160, rasterizer/function.py:42-95 chained by renderer.py:23-108)."""
+
+  @staticmethod
+  def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
+              opts: FrameOptions, state: FrameState):
+    global host_syncs
+    lib = _lib.load()
+    _lib.require_gpu(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection)
+    tensors = [t.detach().contiguous() for t in
+               (position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection)]
+    pos, lsc, rot, alog, feat, Tcw, proj = tensors
+    dtype, device = pos.dtype, pos.device
+    assert all(t.dtype == dtype for t in tensors), "render_gaussians: all inputs must share one dtype"
+    config = opts.config
+    n = pos.shape[0]
+    w, h = int(opts.image_size[0]), int(opts.image_size[1])
+    ts = config.tile_size
+    tiles_high = (h + ts - 1) // ts
+
+    if opts.use_sh:
+      assert feat.ndim == 3, f"SH features must have 3 dimensions, got {feat.shape}"
+      f, d = feat.shape[1], feat.shape[2]
+      degree = int(round(d ** 0.5)) - 1
+      assert (degree + 1) ** 2 == d, f"SH feature count must be square, got {d} ({feat.shape})"
+      assert 0 <= degree <= 3, f"SH degree must be between 0 and 3, got {degree}"
+    else:
+      assert feat.ndim == 2, f"Features must be (N, C) if use_sh=False, got {feat.shape}"
+      f, degree = feat.shape[1], -1
+    if config.compute_visibility and not config.use_alpha_blending:
+      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
+                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
+
+    rows = (0, tiles_high) if opts.tile_rows is None else (max(0, int(opts.tile_rows[0])), min(tiles_high, int(opts.tile_rows[1])))
+    key = _shape_key(device, n, (w, h), config, opts.tile_rows, opts.use_depth16)
+    capturing = torch.cuda.is_current_stream_capturing()
+    capacity = _k_capacity.get(key, 0)
+    if capturing and capacity == 0:
+      raise RuntimeError("render_gaussians under HIP-graph capture: the overlap-list capacity of this scene shape is "
+                         "unknown; render one eager frame first or call frame.set_overlap_capacity(...)")
+
+    desc = _lib.FrameDescC(n=n, k_capacity=capacity, image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
+                           sh_degree=degree, depth16=int(opts.use_depth16), tile_row_begin=rows[0], tile_row_end=rows[1],
+                           projected_input=0, reserved=0, near_plane=float(opts.depth_range[0]),
+                           far_plane=float(opts.depth_range[1]), blur_cov=float(config.blur_cov),
+                           clamp_margin=float(config.clamp_margin), raster=_lib.raster_config_c(config))
+    layout = _lib.FrameLayoutC()
+    _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(layout)), "render_gaussians")
+    stream = _lib.current_stream(device)
+    keep_n = torch.empty((layout.keep_n_bytes,), dtype=torch.uint8, device=device)
+    scratch_n = torch.empty((layout.scratch_n_bytes,), dtype=torch.uint8, device=device)
+    inputs = _lib.FrameInputsC(position=pos.data_ptr(), log_scaling=lsc.data_ptr(), rotation=rot.data_ptr(),
+                               alpha_logit=alog.data_ptr(), feature=feat.data_ptr(), T_camera_world=Tcw.data_ptr(),
+                               projection=proj.data_ptr(), points7=None, depth=None, colours=None)
+
+    k_word, k_event = (None, None) if capturing else _pinned_k(device)
+    _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                          None if capturing else k_word.data_ptr(), None, stream), "render_gaussians")
+    if not capturing:
+      k_event.record(torch.cuda.current_stream(device))
+
+    # images: with crop_to_rows only the strip's pixel rows exist; the kernels address absolute rows, so they get the
+    # address row 0 WOULD have (they touch rows [y0, y1) only)
+    y0, y1 = _strip_pixels(rows, ts, h) if opts.crop_to_rows else (0, h)
+    image = torch.empty((y1 - y0, w, f), dtype=dtype, device=device)
+    alpha = torch.empty((y1 - y0, w), dtype=dtype, device=device)
+    if not opts.crop_to_rows and rows != (0, tiles_high):
+      image.zero_(); alpha.zero_()
+    visibility = torch.zeros((n,), dtype=dtype, device=device) if config.compute_visibility else torch.empty((0,), dtype=dtype, device=device)
+    heuristic = torch.zeros((n, 2), dtype=dtype, device=device) if config.compute_point_heuristic else torch.empty((0, 2), dtype=dtype, device=device)
+    es = image.element_size()
+
+    def map_raster(cap):
+      desc.k_capacity = cap
+      lay = _lib.FrameLayoutC()
+      _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(lay)), "render_gaussians")
+      keep_k = torch.empty((lay.keep_k_bytes,), dtype=torch.uint8, device=device)
+      scratch_k = torch.empty((lay.scratch_k_bytes,), dtype=torch.uint8, device=device)
+      _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                         keep_k.data_ptr(), scratch_k.data_ptr(),
+                                         image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es,
+                                         visibility.data_ptr() if config.compute_visibility else None, stream),
+                 "render_gaussians")
+      return lay, keep_k
+
+    k_total = None
+    if capturing:
+      layout, keep_k = map_raster(capacity)
+    else:
+      if capacity > 0:
+        layout, keep_k = map_raster(capacity)        # everything is enqueued before the host looks at K
+      k_event.synchronize()
+      host_syncs += 1
+      k_total = int(k_word.item())
+      if k_total < 0:
+        raise OverflowError("render_gaussians: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
+                            "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
+      if capacity == 0 or k_total > capacity:
+        capacity = _round_capacity(k_total * K_SLACK)
+        if config.compute_visibility and k_total > 0:
+          visibility.zero_()
+        layout, keep_k = map_raster(capacity)
+      _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+
+    state.desc, state.layout, state.inputs = desc, layout, inputs
+    state.keep_n, state.keep_k, state.k, state.capacity, state.y0 = keep_n, keep_k, k_total, capacity, y0
+    state.tensors = tensors                                  # the pointers in `inputs` stay valid
+
+    points7 = _view(keep_n, layout.points7, dtype, (n, 7))
+    depth = _view(keep_n, layout.depth, dtype, (n,))
+    colours = _view(keep_n, layout.colours, dtype, (n, f)) if opts.use_sh else None
+
+    median = None
+    if opts.render_median_depth:
+      # renderer.py:77-82: quantile pass over the depths with the same tile lists
+      cfg_m = _lib.raster_config_c(replace(config, use_alpha_blending=False, saturate_threshold=config.median_threshold,
+                                           compute_visibility=False, compute_point_heuristic=False))
+      median = torch.empty((y1 - y0, w, 1), dtype=dtype, device=device)
+      median_alpha = torch.empty((y1 - y0, w), dtype=dtype, device=device)
+      if not opts.crop_to_rows and rows != (0, tiles_high):
+        median.zero_()
+      if y1 > y0:
+        _lib.check(lib.ms_raster_fwd(points7.data_ptr(), depth.data_ptr(), state.tile_ranges().data_ptr(),
+                                     state.overlap_to_point().data_ptr(), w, h, 1, cfg_m,
+                                     median.data_ptr() - y0 * w * es, median_alpha.data_ptr() - y0 * w * es, None,
+                                     rows[0], rows[1], _lib.dtype_code(dtype), stream), "render_gaussians (median depth)")
+      median = median.squeeze(-1)
+
+    ctx.set_materialize_grads(False)
+    ctx.state, ctx.opts = state, opts
+    ctx.f, ctx.degree, ctx.rows = f, degree, rows
+    ctx.save_for_backward(*tensors, image)
+    ctx.heuristic = heuristic
+    non_diff = [alpha, visibility, heuristic] + ([median] if median is not None else [])
+    ctx.mark_non_differentiable(*non_diff)
+    return image, alpha, points7, depth, colours, visibility, heuristic, median
+
+  @staticmethod
+  def backward(ctx, g_image, g_alpha, g_points7, g_depth, g_colours, g_vis, g_heur, g_median):
+    from .rasterizer import function as raster_function
+    lib = _lib.load()
+    pos, lsc, rot, alog, feat, Tcw, proj, image = ctx.saved_tensors
+    state, opts = ctx.state, ctx.opts
+    desc, config = state.desc, opts.config
+    n, f = pos.shape[0], ctx.f
+    device, dtype = pos.device, pos.dtype
+    none = (None,) * 9
+    if g_image is None and g_points7 is None and g_depth is None and g_colours is None:
+      return none
+    need = ctx.needs_input_grad
+    if n == 0 or image.shape[0] == 0:
+      zeros = [torch.zeros_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog, feat, Tcw, proj))]
+      return (*zeros, None, None)
+
+    w, h = opts.image_size
+    g_image = g_image.contiguous() if g_image is not None else torch.zeros_like(image)
+    stream = _lib.current_stream(device)
+    det = bool(raster_function.DETERMINISTIC_BACKWARD)
+    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), int(det)))
+    retained = state.retained()
+    want_points = any(kind == 'points7' for _, _, kind in retained)
+    # camera pose optimisation with SH colours: the view direction depends on the camera position =
+    # inverse(T_camera_world)[:3, 3] (perspective/params.py:62-65; the renderer detaches the gaussians' positions for
+    # the SH evaluation, renderer.py:53, but not the camera's) — needs d(colour) as an array, see below
+    sh_camera = bool(need[5] and opts.use_sh)
+    want_colours = any(kind == 'colours' for _, _, kind in retained) or sh_camera
+
+    gr = _lib.FrameGradsC()
+    row_bytes = state.y0 * w * image.element_size()          # cropped strip: address of the (absent) row 0
+    gr.image = image.data_ptr() - row_bytes * f
+    gr.grad_image = g_image.data_ptr() - row_bytes * f
+    extras = []
+    for name, g in (('extra_points7', g_points7), ('extra_depth', g_depth), ('extra_colours', g_colours)):
+      if g is not None:
+        g = g.contiguous()
+        extras.append(g)
+        setattr(gr, name, g.data_ptr())
+
+    grad_points7 = grad_colours = None
+    fixed_exp = None
+    if moments_path:
+      moments = _moments_buffer(device, n, det)
+      gr.moments = moments.data_ptr()
+      gr.deterministic = int(det)
+      if det:
+        fixed_exp = _lib.fixed_point_exponents(g_image)
+        gr.fixed_exp = fixed_exp.data_ptr()
+      if want_points:
+        grad_points7 = torch.empty((n, 7), dtype=dtype, device=device)
+      if want_colours:
+        grad_colours = torch.empty((n, f), dtype=dtype, device=device)
+    else:
+      grad_points7 = torch.zeros((n, 7), dtype=dtype, device=device)
+      grad_colours = torch.zeros((n, f), dtype=dtype, device=device)
+    gr.grad_points7, gr.grad_colours = _lib.ptr(grad_points7), _lib.ptr(grad_colours)
+
+    grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
+    gr.grad_position, gr.grad_log_scaling, gr.grad_rotation, gr.grad_alpha_logit = (_lib.ptr(t) for t in grads)
+    grad_feature = None
+    if need[4]:
+      if opts.use_sh or moments_path:
+        grad_feature = torch.empty_like(feat)
+        gr.grad_feature = grad_feature.data_ptr()
+      else:
+        grad_feature = grad_colours                 # plain colours: the raster backward's accumulator IS the gradient
+    need_camera = need[5] or need[6]
+    grad_camera = torch.zeros((16,), dtype=dtype, device=device) if need_camera else None
+    gr.grad_camera = _lib.ptr(grad_camera)
+    if config.compute_point_heuristic:
+      gr.point_heuristic = ctx.heuristic.data_ptr()
+
+    try:
+      _lib.check(lib.ms_frame_backward(ctypes.byref(desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
+                                       state.keep_k.data_ptr(), ctypes.byref(gr), stream), "render_gaussians backward")
+    except Exception:
+      _moments.clear()        # the accumulator rows may have been left half-written: start from a fresh buffer
+      raise
+
+    if retained:
+      # gaussians2d.retain_grad() / features.retain_grad() of the reference's trainers (renderer.py:103-108
+      # viewspace_gradient): the 2D-boundary gradients never exist as autograd edges here, so they are handed out
+      if not moments_path:
+        total_p = grad_points7 if g_points7 is None else grad_points7 + g_points7
+        total_c = grad_colours if g_colours is None else grad_colours + g_colours
+      else:
+        total_p, total_c = grad_points7, grad_colours
+      for t, idx, kind in retained:
+        total = total_p if kind == 'points7' else total_c
+        t.grad = (total if idx is None else total[idx]).reshape(t.shape)
+
+    grad_T = grad_proj = None
+    if need_camera:
+      if need[5]:
+        grad_T = torch.zeros((4, 4), dtype=dtype, device=device)
+        grad_T[:3] = grad_camera[:12].view(3, 4)
+        if sh_camera:
+          # d(colour) -> d(camera position) with the direction-gradient kernel of the modular SH operator (it re-reads
+          # the SH rows: a pose-optimisation-only cost), then through the matrix inverse: A = T^-1,
+          # dL/dT = -A^T (dL/dA) A^T with dL/dA non-zero in A[:3, 3] only
+          total_c = grad_colours if (moments_path or g_colours is None) else grad_colours + g_colours
+          g_cam = torch.zeros((3,), dtype=dtype, device=device)
+          cam_pos = _view(state.keep_n, state.layout.camera_position, dtype, (3,))
+          _lib.check(lib.ms_sh_bwd(feat.data_ptr(), pos.data_ptr(), identity_indexes(n, device).data_ptr(), cam_pos.data_ptr(),
+                                   n, f, ctx.degree, None, total_c.data_ptr(), None, None, g_cam.data_ptr(), 0,
+                                   _lib.dtype_code(dtype), stream), "render_gaussians backward (camera position)")
+          A = torch.inverse(Tcw)
+          dA = torch.zeros((4, 4), dtype=dtype, device=device)
+          dA[:3, 3] = g_cam
+          grad_T = grad_T - A.t() @ dA @ A.t()
+      if need[6]:
+        grad_proj = grad_camera[12:16].clone()
+    return (*grads, grad_feature, grad_T, grad_proj, None, None)
+
+
+class LazyPoints:
+  """Builds the ``RenderedPoints`` of a frame on first access (``Rendering.points``): the compacted ``(V, ...)``
+  arrays the reference's projection returns (perspective/projection.py:147-150) are made from the full ones here,
+  with the reference's one host synchronisation on the visible count."""
+
+  def __init__(self, state: FrameState, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh):
+    self.args = (state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh)
+
+  def materialise(self):
+    from .rendering import RenderedPoints
+    global point_syncs
+    state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh = self.args
+    n = depth.shape[0]
+    with torch.no_grad():
+      mask = depth > 0
+      v = int(mask.sum().item())
+    point_syncs += 1
+    if v == n:
+      idx, sel = identity_indexes(n, depth.device), None
+      g2d, dep = points7, depth.unsqueeze(1)
+      feats = colours if use_sh else gaussians.feature[idx]
+      vis = visibility if config.compute_visibility else None
+      heur = heuristic if config.compute_point_heuristic else None
+    else:
+      idx = sel = mask.nonzero().squeeze(1)
+      g2d, dep = points7[idx], depth[idx].unsqueeze(1)
+      feats = colours[idx] if use_sh else gaussians.feature[idx]
+      vis = visibility[idx] if config.compute_visibility else None
+      heur = heuristic[idx] if config.compute_point_heuristic else None
+    if g2d.requires_grad:
+      state.register(g2d, sel, 'points7')
+    if use_sh and feats.requires_grad:
+      state.register(feats, sel, 'colours')
+    return RenderedPoints(
+      idx=idx, depths=dep, gaussians2d=g2d,
+      _visibility=vis,
+      _prune_cost=heur[:, 0] if heur is not None else None,
+      _split_score=heur[:, 1] if heur is not None else None,
+      features=feats, attributes=None, batch_size=(v,))
+
+
+def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, use_depth16: bool = False,
+                 render_median_depth: bool = False, tile_rows=None, crop_to_rows: bool = False):
+  """``render_gaussians`` on the frame executor.  Returns a ``Rendering`` whose ``points`` are built lazily."""
+  from .rendering import Rendering
+  opts = FrameOptions(image_size=tuple(int(x) for x in camera_params.image_size),
+                      depth_range=tuple(float(x) for x in camera_params.depth_range), config=config,
+                      use_sh=bool(use_sh), use_depth16=bool(use_depth16), tile_rows=tile_rows,
+                      crop_to_rows=bool(crop_to_rows), render_median_depth=bool(render_median_depth))
+  state = FrameState()
+  image, alpha, points7, depth, colours, visibility, heuristic, median = _FrameFunction.apply(
+    *gaussians.shape_tensors(), gaussians.feature, camera_params.T_camera_world.reshape(4, 4),
+    camera_params.projection.reshape(4), opts, state)
+  points = LazyPoints(state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh)
+  rendering = Rendering(image=image, image_weight=alpha, depth_image=None, median_depth_image=median, points=points,
+                        camera=camera_params, config=config)
+  object.__setattr__(rendering, 'frame', state)
+  return rendering
+
+
+def frame_status(rendering) -> dict:
+  """Host read of a frame's device-side counters: overlap total, capacity, overflow flag (synchronises)."""
+  state = getattr(rendering, 'frame', None)
+  assert state is not None, "frame_status: not a rendering of the frame executor"
+  k, live, overflow = state.counters()[:3].tolist()
+  return {"overlaps": k, "capacity": state.capacity, "overflow": bool(overflow)}
+
+
+class FrameGraph:
+  """A training / rendering step captured in a HIP graph (``torch.cuda.CUDAGraph``) and replayed with one launch.
+
+  ``step()`` is any callable that renders with ``render_gaussians`` (and usually runs ``backward``) on STATIC tensors:
+  the gaussians' parameter tensors, the camera tensors and whatever the loss reads keep their storage, and new
+  values (a new camera pose, updated parameters) are written into them in place between replays.  The frame executor
+  never goes back to the host, so the whole step — about 35 kernel launches for forward + backward — is one graph.
+  The overlap-list capacity is the one remembered from the eager warm-up frames; ``frame_status(result)`` tells
+  whether a later replay exceeded it (the frame then holds the background only and the step must be re-captured after
+  ``set_overlap_capacity``).  Do not touch ``result.points`` inside ``step`` (it reads the visible count back), and
+  drop every reference to renderings / losses of earlier eager steps first: torch's rule for whole-step capture — an
+  autograd graph created on the default stream that is still alive pulls its gradient accumulation onto that stream
+  and breaks the capture.
+  """
+
+  def __init__(self, step, warmup: int = 2):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      for _ in range(max(1, warmup)):            # eager frames: allocator warm-up and the capacity of this scene shape
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    self.graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self.graph):
+      self.result = step()
+
+  def replay(self):
+    self.graph.replay()
+    return self.result

@@ -181,11 +181,12 @@ class _RasterFunction(torch.autograd.Function):
     if moments_path:
       det = int(DETERMINISTIC_BACKWARD)
       moments = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.int64 if det else torch.float32, device=gaussians.device)
+      fixed_exp = _lib.fixed_point_exponents(grad_image) if det else None
       _lib.check(lib.ms_raster_bwd_moments(gaussians.data_ptr(), features.data_ptr(), ctx.tile_overlap_ranges.data_ptr(),
                                            _lib.ptr(ctx.overlap_to_point), image.data_ptr() - row_bytes * f,
                                            grad_image.data_ptr() - row_bytes * f, w, h, cfg_c, moments.data_ptr(), det,
-                                           ctx.rows[0], ctx.rows[1], stream), "rasterize backward")
-      _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), det, n, _lib.ptr(grad_gaussians),
+                                           _lib.ptr(fixed_exp), ctx.rows[0], ctx.rows[1], stream), "rasterize backward")
+      _lib.check(lib.ms_raster_moments_finalize(gaussians.data_ptr(), moments.data_ptr(), det, _lib.ptr(fixed_exp), n, _lib.ptr(grad_gaussians),
                                                 _lib.ptr(grad_features), _lib.ptr(heuristic), stream),
                  "rasterize backward (moments -> gradients)")
     elif f > MAX_KERNEL_FEATURES and heuristic is not None:

@@ -41,8 +41,14 @@ def render_gaussians(
     render_median_depth: extra quantile pass producing ``median_depth_image``
     tile_rows: optional (begin, end) tile-row strip to render (multi-GPU sharding)
   """
-  # launched before the projection's host synchronisation (visible count) so that the first kernel queued after it
-  # is the long SH pass, not a string of small ones
+  from . import frame
+  if frame.USE_FRAME and frame.frame_supported(gaussians.feature, config, use_sh):
+    # one autograd node on a fixed launch sequence, no host round trip for the visible / overlap counts (frame.py)
+    return frame.render_frame(gaussians, camera_params, config, use_sh, use_depth16=use_depth16,
+                              render_median_depth=render_median_depth, tile_rows=tile_rows)
+
+  # modular composition (wide feature vectors, MS_FRAME=legacy): launched before the projection's host
+  # synchronisation (visible count) so that the first kernel queued after it is the long SH pass
   camera_position = camera_params.camera_position if use_sh else None
   gaussians2d, depths, indexes = project_to_image(gaussians, camera_params, config)
 

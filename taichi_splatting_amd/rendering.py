@@ -121,6 +121,15 @@ class Rendering:
   median_depth_image: Optional[torch.Tensor] = None   # (H, W)
   glo_feature: Optional[torch.Tensor] = None
 
+  def __getattribute__(self, name):
+    # the frame executor (frame.py) does not compact the visible gaussians; `points` then holds a LazyPoints that
+    # builds the (V, ...) arrays — with the host read of V the reference does in its projection — on first access
+    value = object.__getattribute__(self, name)
+    if name == 'points' and hasattr(value, 'materialise'):
+      value = value.materialise()
+      object.__setattr__(self, 'points', value)
+    return value
+
   @cached_property
   def ndc_image(self) -> torch.Tensor:
     return ndc_depth(self.depth_image, self.camera.near_plane, self.camera.far_plane)

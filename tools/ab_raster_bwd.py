@@ -81,11 +81,11 @@ def main():
 
     def new_main():
       _lib.check(lib.ms_raster_bwd_moments(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
-                                           image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, 0, th,
+                                           image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0, th,
                                            stream), "new")
 
     def new_fin():
-      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), mom.data_ptr(), 0, n, gp1.data_ptr(), gf1.data_ptr(),
+      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), mom.data_ptr(), 0, None, n, gp1.data_ptr(), gf1.data_ptr(),
                                                 _lib.ptr(he1), stream), "fin")
 
     import ctypes

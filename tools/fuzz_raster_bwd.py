@@ -87,10 +87,11 @@ def main():
         mom = torch.zeros((n, _lib.MOMENT_ROW), device=dev, dtype=torch.int64 if det else torch.float32)
         gp1, gf1 = torch.empty_like(g2d), torch.empty_like(feats)
         he1 = torch.empty((n, 2), device=dev) if heur else None
+        fexp = _lib.fixed_point_exponents(grad_image) if det else None
         _lib.check(lib.ms_raster_bwd_moments(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
                                              image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), det,
-                                             row0, row1, stream), "moments")
-        _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), mom.data_ptr(), det, n, gp1.data_ptr(), gf1.data_ptr(),
+                                             _lib.ptr(fexp), row0, row1, stream), "moments")
+        _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), mom.data_ptr(), det, _lib.ptr(fexp), n, gp1.data_ptr(), gf1.data_ptr(),
                                                   _lib.ptr(he1), stream), "finalize")
         torch.cuda.synchronize()
         # per splat: largest difference over its outputs, each relative to the largest gradient of that output
