@@ -52,6 +52,9 @@ def parse_args():
                       'all-to-all of projected splats; strips = replicated gaussians + all-reduce (north_star); '
                       'auto = both for N > 1 (value = the faster one)')
   p.add_argument('--forward-only', action='store_true')
+  p.add_argument('--no-graph', action='store_true', help='skip the HIP-graph replay timing of the same step')
+  p.add_argument('--graph-child', action='store_true', help=argparse.SUPPRESS)
+  p.add_argument('--no-sweep', action='store_true', help='skip the tile 8 / 16 / 32 sweep (BASELINE.json configs[3])')
   p.add_argument('--even-strips', action='store_true', help='N > 1: equal tile rows per rank instead of overlap-balanced strips')
   p.add_argument('--launcher', action='store_true',
                  help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
@@ -129,7 +132,6 @@ def stage_breakdown(g, cam, cfg, use_sh):
     # the dominant kernel, timed alone through the C-ABI
     grad_image = torch.ones_like(image)
     moments = torch.zeros((g2d.shape[0], _lib.MOMENT_ROW), dtype=torch.float32, device=g2d.device)
-    gp, gf = torch.empty_like(g2d), torch.empty_like(feats)
     cfg_c = _lib.raster_config_c(cfg)
     w, h = cam.image_size
     stream = _lib.current_stream(g2d.device)
@@ -140,11 +142,25 @@ def stage_breakdown(g, cam, cfg, use_sh):
                                            image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, moments.data_ptr(),
                                            0, None, 0, tiles_high, stream), "bench raster_bwd")
 
-    def fin():
-      _lib.check(lib.ms_raster_moments_finalize(g2d.data_ptr(), moments.data_ptr(), 0, None, g2d.shape[0], gp.data_ptr(),
-                                                gf.data_ptr(), None, stream), "bench raster finalize")
     out['raster_bwd'] = cuda_time_ms(bwd, iters=10, warmup=2)
-    out['raster_bwd_finalize'] = cuda_time_ms(fin, iters=10, warmup=2)
+    moments.zero_()
+  # the executor's backward = raster backward + ONE pass over the gaussians (moments -> 2D gradients -> projection
+  # backward -> SH backward, csrc/gaussian_bwd.hip): timed as the whole backward call minus the raster kernel
+  from taichi_splatting_amd import render_gaussians
+  g.requires_grad_(True)
+  r = render_gaussians(g, cam, cfg, use_sh=use_sh)
+  loss = r.image.sum()
+  leaves = (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature)
+
+  def backward():
+    for t in leaves:
+      t.grad = None               # the first accumulation of a backward pass takes the gradient tensor as it is
+    loss.backward(retain_graph=True)
+  out['backward_total'] = cuda_time_ms(backward, iters=10, warmup=2)
+  out['gaussian_bwd'] = max(out['backward_total'] - out['raster_bwd'], 0.0)
+  g.requires_grad_(False)
+  for t in (g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature):
+    t.grad = None
   return out, int(idx.shape[0]), int(o2p.shape[0])
 
 
@@ -270,12 +286,15 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
   torch.cuda.synchronize()
   log(f"[{mode}] {args.warmup} warmup steps done")
 
+  from taichi_splatting_amd import frame as frame_mod
   barrier()
+  syncs0 = frame_mod.host_syncs + frame_mod.point_syncs
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
   torch.cuda.synchronize()
   mine = time.perf_counter() - t0            # this rank's own time (before waiting for the slowest)
+  comm['host_syncs_per_step'] = (frame_mod.host_syncs + frame_mod.point_syncs - syncs0) / max(args.steps, 1)
   barrier()
   elapsed = time.perf_counter() - t0
   per_rank = [mine]
@@ -293,6 +312,8 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
 
 def main():
   args = parse_args()
+  if args.graph_child:
+    return graph_child(args)
   in_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
   if (args.gpus > 1 or args.launcher) and not in_launcher:
     respawn_under_torchrun(args)             # does not return
@@ -332,6 +353,7 @@ def main():
     ms = elapsed / args.steps * 1e3
     log(f"[{mode}] timed {args.steps} steps: {ms:.3f} ms/step")
     runs[mode] = {"ms_per_step": round(ms, 3), "value": round(args.n / (ms * 1e-3) / 1e6, 2),
+                  "host_syncs_per_step": comm.pop('host_syncs_per_step', None),
                   "strips": "even tile rows" if args.even_strips or world == 1 else "overlap-balanced",
                   "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
                   "rank0_exchange_bytes_per_step": comm or None}
@@ -360,8 +382,26 @@ def main():
                                           "all-to-all of projected splats and of their gradients",
                                "strips": f"replicated gaussians, tile-row strips x{world}, all-reduce of 2D-boundary grads"}[mode]},
   }
+  result["host_syncs_per_step"] = runs[mode]["host_syncs_per_step"]
   if world > 1:
     result["modes"] = runs
+  else:
+    result["host_sync_note"] = ("the one wait per frame is on the overlap total, AFTER the whole forward pass is "
+                                "enqueued (the GPU never idles for it); 0 inside a captured HIP graph")
+
+  if rank == 0 and mode == 'single' and not args.forward_only and not args.no_graph:
+    # the same step captured in a HIP graph (frame.FrameGraph): no host work between the ~35 launches of a frame.
+    # Timed in a child process: a capture that goes wrong takes the process down, and the line above must survive it
+    result["graph_ms_per_step"] = graph_step_ms_in_child(args)
+    log(f"[single] HIP-graph replay: {result['graph_ms_per_step']} ms/step")
+  if rank == 0 and mode == 'single' and not args.forward_only and not args.no_sweep:
+    # BASELINE.json configs[3] names the tile-size sweep: the other two sizes, same scene, fewer frames
+    sweep = {str(args.tile): ms_per_step}
+    for ts in (8, 16, 32):
+      if ts != args.tile:
+        sweep[str(ts)] = round(tile_step_ms(g, cam, ts, max(10, args.steps // 5)), 3)
+    result["tile_sweep_ms"] = dict(sorted(sweep.items(), key=lambda kv: int(kv[0])))
+    log(f"tile sweep {result['tile_sweep_ms']}")
 
   if rank == 0 and not args.no_stages and mode == 'single':
     g.requires_grad_(False)
@@ -375,11 +415,12 @@ def main():
     alg = algorithmic_bytes(args.n, V, K, P, T, F, D, ref_passes)
     dom = 'raster_bwd'
     achieved = alg[dom] / (stages[dom] * 1e-3) / 1e9
-    traffic, compute = load_counters(args, w, h)
+    traffic, compute, provenance = load_counters(args, w, h)
     result["roofline"] = {"bound": "hbm", "kernel": "raster_bwd_scan_kernel<%d,false>" % args.tile,
                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                           "kernel_ms": round(stages[dom], 4), "algorithmic_bytes": alg[dom],
+                          "counters": provenance,
                           "note": "alpha-composite passes are VALU bound at these K*tile^2 (SURVEY 8d); see compute"}
     if compute:
       result["roofline"]["compute"] = compute
@@ -404,17 +445,112 @@ def main():
     dist.destroy_process_group()
 
 
+COUNTER_FILE = ROOT / 'profiles' / 'raster_bwd_counters.json'
+COUNTER_SOURCES = ('raster_bwd_scan.hip', 'raster_common.h', 'common.h')
+
+
+def kernel_source_sha16():
+  """Fingerprint of the sources the dominant kernel is compiled from: the PMC figures are attached to the bench line
+  only when they were collected on exactly this code (tools/pmc_to_profile.py stores the same fingerprint)."""
+  import hashlib
+  h = hashlib.sha256()
+  for name in COUNTER_SOURCES:
+    h.update((ROOT / 'taichi_splatting_amd' / 'csrc' / name).read_bytes())
+  return h.hexdigest()[:16]
+
+
 def load_counters(args, w, h):
   """HBM bytes per launch and VALU figures of the dominant kernel from the committed rocprofv3 PMC passes
-  (profiles/r02_raster_bwd_counters.json), valid only for the workload they were collected on."""
+  (profiles/raster_bwd_counters.json; rocprofv3 --pmc cannot run inside the timed bench process).  They describe ONE
+  binary on ONE workload: returned only if the workload matches and the kernel sources are byte-identical to the
+  ones profiled; otherwise `traffic` is null and the provenance field says why."""
   try:
-    t = json.load(open(ROOT / 'profiles' / 'r02_raster_bwd_counters.json'))
-    wl = t['workload']
-    if (wl['n'], wl['width'], wl['height'], wl['tile']) != (args.n, w, h, args.tile):
-      return None, None
-    return t.get('traffic_bytes'), t.get('compute')
+    t = json.load(open(COUNTER_FILE))
   except Exception:
-    return None, None
+    return None, None, "no counter file"
+  wl = t['workload']
+  if (wl['n'], wl['width'], wl['height'], wl['tile']) != (args.n, w, h, args.tile):
+    return None, None, "counter file is for another workload"
+  have, now = t.get('kernel_source_sha16'), kernel_source_sha16()
+  if have != now:
+    return None, None, f"stale: collected on kernel sources {have}, this tree is {now} (tools/refresh_profiles.sh)"
+  return t.get('traffic_bytes'), t.get('compute'), {"file": str(COUNTER_FILE.relative_to(ROOT)), "kernel_source_sha16": have,
+                                                    "collected": t.get('collected')}
+
+
+def graph_step_ms_in_child(args):
+  import subprocess
+  cmd = [sys.executable, str(Path(__file__).resolve()), '--graph-child', '--steps', str(args.steps), '--n', str(args.n),
+         '--size', str(args.size), '--tile', str(args.tile), '--sh-degree', str(args.sh_degree), '--seed', str(args.seed)]
+  if args.height:
+    cmd += ['--height', str(args.height)]
+  try:
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    for line in out.stdout.splitlines():
+      if line.startswith('GRAPH_MS '):
+        return round(float(line.split()[1]), 3)
+    log(f"graph child: no result (rc {out.returncode}): {out.stderr[-300:]}")
+  except Exception as e:
+    log(f"graph child failed: {e!r}")
+  return None
+
+
+def graph_child(args):
+  from taichi_splatting_amd import RasterConfig
+  device = torch.device('cuda', 0)
+  torch.cuda.set_device(device)
+  cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  scene, cam = make_scene(args, device)
+  print(f"GRAPH_MS {graph_step_ms(scene, cam, cfg, args.steps)}", flush=True)
+
+
+def graph_step_ms(g, cam, cfg, steps):
+  from taichi_splatting_amd import frame, render_gaussians
+  g.requires_grad_(True)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+
+  def step():
+    for t in leaves:
+      t.grad = None
+    render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
+  graph = frame.FrameGraph(step, warmup=2)
+  for _ in range(3):
+    graph.replay()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    graph.replay()
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / steps * 1e3
+  del graph
+  g.requires_grad_(False)
+  for t in leaves:
+    t.grad = None
+  return ms
+
+
+def tile_step_ms(g, cam, tile, steps):
+  from taichi_splatting_amd import RasterConfig, render_gaussians
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
+  g.requires_grad_(True)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+
+  def step():
+    for t in leaves:
+      t.grad = None
+    render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
+  for _ in range(3):
+    step()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  torch.cuda.synchronize()
+  ms = (time.perf_counter() - t0) / steps * 1e3
+  g.requires_grad_(False)
+  for t in leaves:
+    t.grad = None
+  return ms
 
 
 if __name__ == '__main__':

@@ -246,7 +246,9 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  *   scratch_n / scratch_k   dead once the forward calls returned (stream order)
  * counters (int32[8] at lay.counters in keep_n): [0] K, [1] live K (0 on overflow), [2] overflow flag.
  *
- * ms_frame_project_count:  camera position, projection, SH colours, depth pre-sort, overlap count, scan, K.
+ * ms_frame_project:        the per-gaussian stage alone (camera position, projection, SH colours) into keep_n — what a
+ *     rank of the gaussian-sharded multi-GPU step runs on its shard before the exchange.
+ * ms_frame_project_count:  ms_frame_project, then depth pre-sort, overlap count, scan, K.
  *     projected_input != 0 (2-D path, splats received for a multi-GPU strip): in->points7 / depth / colours are
  *     used as they are and nothing is culled by depth.  k_host (pinned host int32, may be NULL) receives K;
  *     k_event (hipEvent_t, may be NULL) is recorded right after the kernel that writes it.
@@ -287,12 +289,18 @@ typedef struct ms_frame_inputs {
   const void *points7, *depth, *colours;       /* projected_input */
 } ms_frame_inputs;
 
+enum { MS_BACKWARD_ALL = 0, MS_BACKWARD_GAUSSIANS = 1, MS_BACKWARD_RASTER = 2 };
+
 typedef struct ms_frame_grads {
   const void* image;               /* forward image (H, W, f) */
   const void* grad_image;
   const void *extra_points7, *extra_depth, *extra_colours;   /* dL/d(frame's own per-gaussian outputs), may be NULL */
   void* moments;
-  int32_t deterministic, reserved;
+  int32_t deterministic;
+  int32_t stage;                   /* MS_BACKWARD_ALL, or one half of it around a multi-GPU gradient collective:
+                                      MS_BACKWARD_RASTER stops after the raster backward and STORES the 2D-boundary
+                                      gradients in grad_points7 / grad_colours; MS_BACKWARD_GAUSSIANS runs only the
+                                      per-gaussian pass on the gradients GIVEN in those two arrays */
   const int32_t* fixed_exp;
   void *grad_points7, *grad_colours;   /* moments path: optional stores of the summed 2D-boundary gradients */
   void *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit, *grad_feature, *grad_camera;
@@ -301,6 +309,7 @@ typedef struct ms_frame_grads {
 
 int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
 int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic);
+int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream);
 int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
                            int32_t* k_host, void* k_event, void* stream);
 int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
@@ -364,14 +373,22 @@ int ms_camera_position(const void* t_camera_world, void* out_position3, int dtyp
  * ms_strip_return_grads: backward of the exchange on the sending side: back_rows (S, 7 + f) =
  *   [d packed 2D | d colour] of every slot of the send buffer, summed into the zero-initialised
  *   grad_points7 (V, 7) / grad_features (V, f) of the local splats (grad[send_index[slot]] += row);
- *   route = out_route of ms_strip_route_count (splats with one copy are stored, not accumulated). */
+ *   route = out_route of ms_strip_route_count (splats with one copy are stored, not accumulated); slots with
+ *   send_index < 0 (unused rows of fixed buckets) are skipped. */
 int ms_strip_route_blocks(int v);
-int ms_strip_route_count(const float* points7, int v, int image_h, int tile_size, float alpha_threshold,
+int ms_strip_route_count(const float* points7, const float* depth /* NULL, or (v): rows with depth <= 0 are culled */,
+                         int v, int image_h, int tile_size, float alpha_threshold,
                          const int32_t* bounds_host, int world, int32_t* out_route,
                          int32_t* out_block_counts, int64_t* out_send_counts, void* stream);
+/* bucket_capacity > 0: FIXED buckets — destination r owns rows [r * capacity, (r + 1) * capacity) of out_rows, so
+ * the all-to-all has equal splits the host knows without reading the counts back (sync-free rank step, HIP-graph
+ * capture).  The caller zero-fills out_rows (an all-zero row is a splat with alpha 0: it overlaps no tile and gets
+ * no gradient) and fills out_send_index with -1 first; rows beyond a bucket's capacity are dropped and
+ * *overflow_flag (device int32, may be NULL) is set.  bucket_capacity == 0: buckets of exactly send_counts[r] rows. */
 int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
                         const int64_t* ids, int f, int v, int world, int64_t index_offset,
                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                        int64_t bucket_capacity, int32_t* overflow_flag,
                         float* out_rows, int64_t* out_send_index, void* stream);
 int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, float* out_features,
                     float* out_depths, int64_t* out_ids, void* stream);

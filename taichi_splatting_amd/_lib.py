@@ -20,6 +20,7 @@ CSRC_DIR = PACKAGE_DIR / 'csrc'
 LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB') or PACKAGE_DIR / 'libmi355_splat.so')   # env override: profiling builds
 
 MS_F32, MS_F64 = 0, 1
+BACKWARD_ALL, BACKWARD_GAUSSIANS, BACKWARD_RASTER = 0, 1, 2   # ms_frame_grads.stage
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
 
 _lib: Optional[ctypes.CDLL] = None
@@ -75,7 +76,7 @@ class FrameGradsC(ctypes.Structure):
   _fields_ = [
     ('image', c_void_p), ('grad_image', c_void_p),
     ('extra_points7', c_void_p), ('extra_depth', c_void_p), ('extra_colours', c_void_p),
-    ('moments', c_void_p), ('deterministic', c_int32), ('reserved', c_int32), ('fixed_exp', c_void_p),
+    ('moments', c_void_p), ('deterministic', c_int32), ('stage', c_int32), ('fixed_exp', c_void_p),
     ('grad_points7', c_void_p), ('grad_colours', c_void_p),
     ('grad_position', c_void_p), ('grad_log_scaling', c_void_p), ('grad_rotation', c_void_p),
     ('grad_alpha_logit', c_void_p), ('grad_feature', c_void_p), ('grad_camera', c_void_p),
@@ -104,8 +105,8 @@ SIGNATURES = {
   'ms_morton_codes64': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
   'ms_camera_position': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
   'ms_strip_route_blocks': (c_int, [c_int]),
-  'ms_strip_route_count': (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-  'ms_strip_route_pack': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 5 + [c_void_p]),
+  'ms_strip_route_count': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_strip_route_pack': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 3 + [c_int64, c_void_p] + [c_void_p] * 2 + [c_void_p]),
   'ms_strip_unpack': (c_int, [c_void_p, c_int64, c_int] + [c_void_p] * 4 + [c_void_p]),
   'ms_strip_return_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
   'ms_fractional_update': (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
@@ -115,6 +116,7 @@ SIGNATURES = {
   'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_frame_layout_query': (c_int, [POINTER(FrameDescC), POINTER(FrameLayoutC)]),
   'ms_frame_uses_moments': (c_int, [POINTER(FrameDescC), c_int]),
+  'ms_frame_project': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p]),
   'ms_frame_project_count': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_frame_map_raster': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC)] + [c_void_p] * 8),
   'ms_frame_backward': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, POINTER(FrameGradsC), c_void_p]),

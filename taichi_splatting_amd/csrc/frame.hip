@@ -144,6 +144,29 @@ extern "C" int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministi
     if (rc__ != 0) return rc__; \
   } while (0)
 
+extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_project"));
+  MS_CHECK_ARG(in && keep_n, "null pointer");
+  const ms_frame_desc& d = *desc;
+  MS_CHECK_ARG(!d.projected_input, "projected input has no per-gaussian stage");
+  if (d.n == 0) return 0;
+  ms_frame_layout L;
+  frame_layout(desc, &L);
+  char* kn = (char*)keep_n;
+  MS_CHECK_ARG(in->position && in->log_scaling && in->rotation && in->alpha_logit && in->T_camera_world && in->projection,
+               "null gaussian / camera input");
+  MS_CHECK_ARG(in->feature != nullptr, "feature is null");
+  if (d.sh_degree >= 0)
+    MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
+  MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
+                        d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
+                        d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
+  if (d.sh_degree >= 0)
+    MS_TRY(sh_fwd_inplace_launch(in->feature, in->position, kn + L.depth, kn + L.camera_position, d.n, d.f,
+                                 d.sh_degree, kn + L.colours, d.dtype, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
                                       void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_project_count"));
@@ -167,17 +190,7 @@ extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_
   const void* points7;
   const void* depth;
   if (!d.projected_input) {
-    MS_CHECK_ARG(in->position && in->log_scaling && in->rotation && in->alpha_logit && in->T_camera_world && in->projection,
-                 "null gaussian / camera input");
-    MS_CHECK_ARG(in->feature != nullptr, "feature is null");
-    if (d.sh_degree >= 0)
-      MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
-    MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
-                          d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
-                          d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
-    if (d.sh_degree >= 0)
-      MS_TRY(sh_fwd_inplace_launch(in->feature, in->position, kn + L.depth, kn + L.camera_position, d.n, d.f,
-                                   d.sh_degree, kn + L.colours, d.dtype, s));
+    MS_TRY(ms_frame_project(desc, in, keep_n, stream));
     points7 = kn + L.points7;
     depth = kn + L.depth;
   } else {
@@ -255,7 +268,8 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
 extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
                                  const ms_frame_grads* gr, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_backward"));
-  MS_CHECK_ARG(in && keep_n && gr && gr->image && gr->grad_image, "null pointer");
+  MS_CHECK_ARG(in && keep_n && gr, "null pointer");
+  MS_CHECK_ARG(gr->stage == MS_BACKWARD_GAUSSIANS || (gr->image && gr->grad_image), "null image / grad_image");
   const ms_frame_desc& d = *desc;
   const FrameGeom g = frame_geom(desc);
   ms_frame_layout L;
@@ -270,12 +284,19 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
   if (d.n == 0) return 0;
 
-  const bool moments = frame_uses_moments(desc, gr->deterministic);
-  if (moments) {
+  // MS_BACKWARD_GAUSSIANS: the 2D-boundary gradients in grad_points7 / grad_colours come from elsewhere (multi-GPU:
+  // summed over the strips and sent home) — only the per-gaussian pass runs.  MS_BACKWARD_RASTER: the other half
+  const bool given = gr->stage == MS_BACKWARD_GAUSSIANS;
+  const bool raster_only = gr->stage == MS_BACKWARD_RASTER || d.projected_input;
+  const bool moments = !given && frame_uses_moments(desc, gr->deterministic);
+  if (given) {
+    MS_CHECK_ARG(!d.projected_input, "projected input has no per-gaussian backward");
+    MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
+  } else if (moments) {
     MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
     MS_TRY(ms_raster_bwd_moments(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
                                  (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end, stream));
-    if (d.projected_input)
+    if (raster_only)
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,
                                             d.raster.compute_point_heuristic ? (float*)gr->point_heuristic : nullptr, s);
@@ -284,7 +305,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     MS_TRY(ms_raster_bwd(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, d.f, &d.raster,
                          gr->grad_points7, gr->grad_colours, d.raster.compute_point_heuristic ? gr->point_heuristic : nullptr,
                          g.row_begin, g.row_end, d.dtype, stream));
-    if (d.projected_input) return 0;
+    if (raster_only) return 0;
   }
 
   GaussianBwdArgs a{};

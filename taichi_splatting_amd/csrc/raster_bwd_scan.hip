@@ -560,23 +560,29 @@ raster_moments_finalize_kernel(const float* __restrict__ points, float* __restri
   if (grad_points) {
     const float* g = points + i * 7;
     const float ax = g[2], ay = g[3], sx = g[4], sy = g[5], alpha = g[6];
-    // a splat the rasterizer can never blend (alpha or a sigma of 0: masked / underflowed parameters of a direct
-    // rasterize() caller) has an all-zero row; its gradient is exactly zero like the atomic path's (0 / 0 otherwise)
+    // a splat the rasterizer can never blend (alpha or a sigma of 0 or NaN: masked / underflowed parameters of a direct
+    // rasterize() caller, padding rows, culled rows of the frame executor) has an all-zero row; its gradient is
+    // exactly zero like the atomic path's (0 / 0 or 0 * NaN otherwise)
     const bool dead = !(alpha > 0.0f) || !(sx > 0.0f) || !(sy > 0.0f);
-    const float isx = dead ? 0.0f : 1.0f / sx, isy = dead ? 0.0f : 1.0f / sy;
-    const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
-    constexpr float IS = 1.0f / EXP2_BASIS_SCALE, IS2 = IS * IS;
-    const float S = r0.x, Sx = r0.y * IS, Sy = r0.z * IS, Sxx = r0.w * IS2, Sxy = r1.x * IS2, Syy = r1.y * IS2;
-    const float det = A * D - B * C;
-    const float idet = det != 0.0f ? 1.0f / det : 0.0f;
     float* o = grad_points + i * 7;
-    o[0] = Sx * A + Sy * C;
-    o[1] = Sx * B + Sy * D;
-    o[2] = -(isx * (D * Sxx - B * Sxy) + isy * (A * Syy - C * Sxy)) * idet;
-    o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
-    o[4] = isx * Sxx;
-    o[5] = isy * Syy;
-    o[6] = dead ? 0.0f : S / alpha;
+    if (dead) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) o[k] = 0.0f;
+    } else {
+      const float isx = 1.0f / sx, isy = 1.0f / sy;
+      const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
+      constexpr float IS = 1.0f / EXP2_BASIS_SCALE, IS2 = IS * IS;
+      const float S = r0.x, Sx = r0.y * IS, Sy = r0.z * IS, Sxx = r0.w * IS2, Sxy = r1.x * IS2, Syy = r1.y * IS2;
+      const float det = A * D - B * C;
+      const float idet = det != 0.0f ? 1.0f / det : 0.0f;
+      o[0] = Sx * A + Sy * C;
+      o[1] = Sx * B + Sy * D;
+      o[2] = -(isx * (D * Sxx - B * Sxy) + isy * (A * Syy - C * Sxy)) * idet;
+      o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
+      o[4] = isx * Sxx;
+      o[5] = isy * Syy;
+      o[6] = S / alpha;
+    }
   }
   if (HEUR && heuristic) {                       // backward.py:190-194: sum (alpha d_alpha)^2, sum |d mean|_1
     const float alpha = points[i * 7 + 6];

@@ -53,15 +53,18 @@ __device__ __forceinline__ void route_of(const float* __restrict__ g, int image_
 }
 
 __global__ void __launch_bounds__(ROUTE_BLOCK)
-route_count_kernel(const float* __restrict__ points7, int v, int image_h, int tile_size, float alpha_threshold,
-                   StripBounds sb, int nblocks, int32_t* __restrict__ route, int32_t* __restrict__ block_counts) {
+route_count_kernel(const float* __restrict__ points7, const float* __restrict__ depth, int v, int image_h, int tile_size,
+                   float alpha_threshold, StripBounds sb, int nblocks, int32_t* __restrict__ route,
+                   int32_t* __restrict__ block_counts) {
   __shared__ int s_count[ROUTE_MAX_WORLD];
   if (threadIdx.x < ROUTE_MAX_WORLD) s_count[threadIdx.x] = 0;
   __syncthreads();
   const int i = blockIdx.x * ROUTE_BLOCK + threadIdx.x;
   if (i < v) {
-    int first, copies;
-    route_of(points7 + (int64_t)i * 7, image_h, tile_size, alpha_threshold, sb, first, copies);
+    int first = 0, copies = 0;
+    // frame executor: the projection does not compact; a culled gaussian (depth <= 0) goes nowhere
+    if (!depth || depth[i] > 0.0f)
+      route_of(points7 + (int64_t)i * 7, image_h, tile_size, alpha_threshold, sb, first, copies);
     route[i] = first | (copies << 16);
     for (int d = first; d < first + copies; ++d) atomicAdd(&s_count[d], 1);
   }
@@ -103,7 +106,8 @@ __global__ void __launch_bounds__(ROUTE_BLOCK)
 route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ feats, const float* __restrict__ depths,
                   const int64_t* __restrict__ ids, int f, int v, int world, int nblocks, int64_t index_offset,
                   const int32_t* __restrict__ route, const int32_t* __restrict__ block_offsets,
-                  const int64_t* __restrict__ send_counts, float* __restrict__ rows, int64_t* __restrict__ send_index) {
+                  const int64_t* __restrict__ send_counts, int64_t bucket_capacity, int32_t* __restrict__ overflow,
+                  float* __restrict__ rows, int64_t* __restrict__ send_index) {
   constexpr int WAVES = ROUTE_BLOCK / 64;
   __shared__ int s_wave_count[WAVES][ROUTE_MAX_WORLD];
   __shared__ int64_t s_bucket_start[ROUTE_MAX_WORLD];
@@ -112,8 +116,14 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
   int first = 0, copies = 0;
   if (i < v) { const int r = route[i]; first = r & 0xffff; copies = r >> 16; }
   if (threadIdx.x == 0) {
+    // bucket_capacity > 0: every destination owns a FIXED range of `bucket_capacity` rows (the all-to-all then has
+    // equal splits known to the host without reading the counts back); rows that do not fit are dropped and flagged
     int64_t acc = 0;
-    for (int d = 0; d < world; ++d) { s_bucket_start[d] = acc; acc += send_counts[d]; }
+    for (int d = 0; d < world; ++d) {
+      s_bucket_start[d] = bucket_capacity > 0 ? (int64_t)d * bucket_capacity : acc;
+      acc += send_counts[d];
+      if (bucket_capacity > 0 && blockIdx.x == 0 && send_counts[d] > bucket_capacity && overflow) *overflow = 1;
+    }
   }
   // wave totals per destination -> LDS (uniform loop: every lane takes part in every ballot)
   for (int d = 0; d < world; ++d) {
@@ -138,8 +148,9 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
     if (!in) continue;
     int before = 0;
     for (int w = 0; w < wave; ++w) before += s_wave_count[w][d];
-    const int64_t slot = s_bucket_start[d] + block_offsets[(int64_t)d * nblocks + blockIdx.x] + before +
-                         __popcll(m & lt_mask);
+    const int64_t in_bucket = (int64_t)block_offsets[(int64_t)d * nblocks + blockIdx.x] + before + __popcll(m & lt_mask);
+    if (bucket_capacity > 0 && in_bucket >= bucket_capacity) continue;
+    const int64_t slot = s_bucket_start[d] + in_bucket;
     float* row = rows + slot * width;
 #pragma unroll
     for (int k = 0; k < 7; ++k) row[k] = g[k];
@@ -177,6 +188,7 @@ return_grads_kernel(const float* __restrict__ back, const int64_t* __restrict__ 
   const int64_t slot = e / width;
   const int k = (int)(e - slot * width);
   const int64_t i = send_index[slot];
+  if (i < 0) return;                      // unused slot of a fixed-capacity bucket
   float* dst = k < 7 ? grad_points7 + i * 7 + k : grad_feats + i * f + (k - 7);
   const float v = back[e];
   if ((route[i] >> 16) == 1) *dst = v;
@@ -210,8 +222,8 @@ static int fill_bounds(const int32_t* bounds, int world, int image_h, int tile_s
 
 extern "C" int ms_strip_route_blocks(int v) { return (int)div_up(v > 0 ? v : 1, ROUTE_BLOCK); }
 
-extern "C" int ms_strip_route_count(const float* points7, int v, int image_h, int tile_size, float alpha_threshold,
-                                    const int32_t* bounds_host, int world, int32_t* out_route,
+extern "C" int ms_strip_route_count(const float* points7, const float* depth, int v, int image_h, int tile_size,
+                                    float alpha_threshold, const int32_t* bounds_host, int world, int32_t* out_route,
                                     int32_t* out_block_counts, int64_t* out_send_counts, void* stream) {
   MS_CHECK_ARG(v >= 0 && image_h > 0 && tile_size > 0, "bad sizes");
   MS_CHECK_ARG(out_block_counts && out_send_counts && (v == 0 || (points7 && out_route)), "null pointer");
@@ -220,7 +232,7 @@ extern "C" int ms_strip_route_count(const float* points7, int v, int image_h, in
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int nblocks = ms_strip_route_blocks(v);
-  route_count_kernel<<<nblocks, ROUTE_BLOCK, 0, s>>>(points7, v, image_h, tile_size, alpha_threshold, sb, nblocks,
+  route_count_kernel<<<nblocks, ROUTE_BLOCK, 0, s>>>(points7, depth, v, image_h, tile_size, alpha_threshold, sb, nblocks,
                                                      out_route, out_block_counts);
   route_offsets_kernel<<<world, 1024, 0, s>>>(out_block_counts, nblocks, out_send_counts);
   MS_CHECK_LAUNCH();
@@ -230,6 +242,7 @@ extern "C" int ms_strip_route_count(const float* points7, int v, int image_h, in
 extern "C" int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
                                    const int64_t* ids, int f, int v, int world, int64_t index_offset,
                                    const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                                   int64_t bucket_capacity, int32_t* overflow_flag,
                                    float* out_rows, int64_t* out_send_index, void* stream) {
   MS_CHECK_ARG(v >= 0 && f >= 0 && world >= 1 && world <= ROUTE_MAX_WORLD, "bad sizes");
   if (v == 0) return 0;
@@ -238,7 +251,8 @@ extern "C" int ms_strip_route_pack(const float* points7, const float* features, 
   const int nblocks = ms_strip_route_blocks(v);
   route_pack_kernel<<<nblocks, ROUTE_BLOCK, 0, (hipStream_t)stream>>>(points7, features, depths, ids, f, v, world,
                                                                        nblocks, index_offset, route, block_offsets,
-                                                                       send_counts, out_rows, out_send_index);
+                                                                       send_counts, bucket_capacity, overflow_flag,
+                                                                       out_rows, out_send_index);
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -355,7 +355,7 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
     send_counts_t = torch.empty((world,), dtype=torch.int64, device=g2d.device)
     import ctypes
     bounds_c = (ctypes.c_int32 * (world + 1))(*[int(b) for b in bounds])
-    _lib.check(lib.ms_strip_route_count(_lib.ptr(g2d), n, int(image_size[1]), config.tile_size,
+    _lib.check(lib.ms_strip_route_count(_lib.ptr(g2d), None, n, int(image_size[1]), config.tile_size,
                                         config.alpha_threshold, ctypes.cast(bounds_c, ctypes.c_void_p), world,
                                         _lib.ptr(route), _lib.ptr(block_offsets), _lib.ptr(send_counts_t), stream),
                'ms_strip_route_count')
@@ -381,7 +381,7 @@ def exchange_to_strips(gaussians2d: torch.Tensor, features: torch.Tensor, depths
     if total > 0:         # nothing to pack when no local splat reaches any strip (all of them below the alpha gate)
       _lib.check(lib.ms_strip_route_pack(_lib.ptr(g2d), _lib.ptr(feats), _lib.ptr(dep), _lib.ptr(ids), f, n,
                                          world, int(index_offset), _lib.ptr(route), _lib.ptr(block_offsets),
-                                         _lib.ptr(send_counts_t), _lib.ptr(rows), _lib.ptr(send_index), stream),
+                                         _lib.ptr(send_counts_t), 0, None, _lib.ptr(rows), _lib.ptr(send_index), stream),
                  'ms_strip_route_pack')
   else:
     send_index, _ = expand_routes(first, copies, total)

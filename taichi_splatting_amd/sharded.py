@@ -1,0 +1,419 @@
+"""Sync-free multi-GPU rank steps on the frame executor (new design; the reference renders on one GPU).
+
+One process per GPU.  Both decompositions of ``distributed.py`` as FIXED launch sequences without a host round trip,
+so that a rank enqueues a whole step ahead of its GPU and the step can be captured in a HIP graph:
+
+``StripStep`` (BASELINE.json north_star): gaussians replicated, every rank renders a strip of tile rows; the
+  2D-boundary gradients [d gaussians2d (7) | d colour (F)] are summed with ONE reduce-scatter + ONE all-gather
+  between the raster backward and the per-gaussian backward pass.
+
+``ShardedStep``: gaussians sharded by index AND pixels by strip.  A rank projects its shard, routes the splats into
+  FIXED-capacity per-destination buckets (``ms_strip_route_pack`` with ``bucket_capacity``: the all-to-all has equal
+  splits the host knows without reading counts back; unused bucket rows are all-zero = splats with alpha 0, which
+  overlap no tile and get no gradient), renders its strip from the received rows with the executor's
+  ``projected_input`` mode, and sends the 2D-boundary gradients home through the reverse all-to-all.
+
+What the step of ``distributed.render_sharded_step`` had to wait for — the visible count, the all-to-all split sizes,
+the overlap total — stays on the device here: nothing is compacted, bucket and overlap-list capacities are fixed by
+``probe()`` (a synchronising dry run outside the hot loop, like the strip bounds) and overflow only raises device-side
+flags that ``check()`` reads whenever the caller chooses to synchronise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, frame
+from .data_types import Gaussians3D, RasterConfig
+from .perspective import CameraParams
+
+
+def _exchange_all_to_all(recv: torch.Tensor, send: torch.Tensor, group):
+  """equal-split all-to-all (RCCL: point-to-point sends over the xGMI links); a copy on one rank"""
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    dist.all_to_all_single(recv, send, group=group)
+  else:
+    recv.copy_(send)
+
+
+class StageTimer:
+  """HIP events at the stage boundaries of a rank step (recorded on the step's stream, read after a synchronise):
+  makes an N > 1 bench line interpretable — compute, exchange and host time can be told apart."""
+
+  def __init__(self, enabled: bool):
+    self.enabled = enabled
+    self.marks = []
+    self.totals = {}
+    self.steps = 0
+
+  def mark(self, name: str):
+    if self.enabled:
+      e = torch.cuda.Event(enable_timing=True)
+      e.record()
+      self.marks.append((name, e))
+
+  def end_step(self):
+    """call after a synchronise: folds the marks of the finished step into per-stage totals"""
+    if not self.enabled or len(self.marks) < 2:
+      self.marks = []
+      return
+    for (_, a), (name, b) in zip(self.marks[:-1], self.marks[1:]):
+      self.totals[name] = self.totals.get(name, 0.0) + a.elapsed_time(b)
+    self.marks = []
+    self.steps += 1
+
+  def mean_ms(self):
+    return {k: round(v / max(self.steps, 1), 4) for k, v in self.totals.items()}
+
+
+def _desc(n, image_size, dtype, f, sh_degree, config, depth_range, tile_rows=None, projected=False, capacity=0,
+          depth16=False):
+  w, h = int(image_size[0]), int(image_size[1])
+  ts = config.tile_size
+  tiles_high = (h + ts - 1) // ts
+  rows = (0, tiles_high) if tile_rows is None else (max(0, int(tile_rows[0])), min(tiles_high, int(tile_rows[1])))
+  return _lib.FrameDescC(n=int(n), k_capacity=int(capacity), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=int(f),
+                         sh_degree=int(sh_degree), depth16=int(depth16), tile_row_begin=rows[0], tile_row_end=rows[1],
+                         projected_input=int(projected), reserved=0, near_plane=float(depth_range[0]),
+                         far_plane=float(depth_range[1]), blur_cov=float(config.blur_cov),
+                         clamp_margin=float(config.clamp_margin), raster=_lib.raster_config_c(config)), rows
+
+
+def _layout(desc):
+  lay = _lib.FrameLayoutC()
+  _lib.check(_lib.load().ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(lay)), "frame layout")
+  return lay
+
+
+def _block(nbytes, device):
+  return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+
+
+def _feature_shape(feature: torch.Tensor, use_sh: bool):
+  if use_sh:
+    assert feature.ndim == 3, f"SH features must have 3 dimensions, got {feature.shape}"
+    d = feature.shape[2]
+    degree = int(round(d ** 0.5)) - 1
+    assert (degree + 1) ** 2 == d and 0 <= degree <= 3, f"SH feature count must be 1, 4, 9 or 16, got {d}"
+    return feature.shape[1], degree
+  assert feature.ndim == 2, f"Features must be (N, C) if use_sh=False, got {feature.shape}"
+  return feature.shape[1], -1
+
+
+def _accumulate(leaf: torch.Tensor, grad: Optional[torch.Tensor]):
+  if grad is None or not leaf.requires_grad:
+    return
+  if leaf.grad is None:
+    leaf.grad = grad
+  else:
+    leaf.grad += grad
+
+
+class _RankStep:
+  """what both decompositions share: geometry, capacities, flags, the strip frame + loss"""
+
+  def __init__(self, image_size, config: RasterConfig, depth_range, rank: int, world: int, bounds: Sequence[int],
+               group=None, time_stages: bool = False):
+    self.image_size = (int(image_size[0]), int(image_size[1]))
+    self.config, self.depth_range = config, (float(depth_range[0]), float(depth_range[1]))
+    self.rank, self.world, self.group = int(rank), int(world), group
+    ts = config.tile_size
+    self.tiles_high = (self.image_size[1] + ts - 1) // ts
+    self.bounds = [int(b) for b in bounds]
+    assert len(self.bounds) == world + 1 and self.bounds[0] == 0 and self.bounds[-1] == self.tiles_high, \
+      f"bounds must run from 0 to tiles_high = {self.tiles_high} over {world} ranks, got {self.bounds}"
+    self.rows = (self.bounds[rank], self.bounds[rank + 1])
+    h = self.image_size[1]
+    self.px_rows = (min(self.rows[0] * ts, h), min(self.rows[1] * ts, h))
+    self.k_capacity = 0
+    self.timer = StageTimer(time_stages)
+    self.flags = None            # device int32[2]: bucket overflow, (unused)
+    self.last_counters = None    # counters view of the last strip frame
+    self.comm_bytes = {}
+
+  def _strip_forward(self, desc, inputs, device, dtype, f):
+    """mapper + raster forward of this rank's strip: returns (keep_n, keep_k, image (strip rows only), alpha)"""
+    lib = _lib.load()
+    stream = _lib.current_stream(device)
+    lay = _layout(desc)
+    keep_n, scratch_n = _block(lay.keep_n_bytes, device), _block(lay.scratch_n_bytes, device)
+    keep_k, scratch_k = _block(lay.keep_k_bytes, device), _block(lay.scratch_k_bytes, device)
+    _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                          None, None, stream), "rank step (map)")
+    w = self.image_size[0]
+    y0, y1 = self.px_rows
+    image = torch.empty((y1 - y0, w, f), dtype=dtype, device=device)
+    alpha = torch.empty((y1 - y0, w), dtype=dtype, device=device)
+    es = image.element_size()
+    _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                       keep_k.data_ptr(), scratch_k.data_ptr(), image.data_ptr() - y0 * w * f * es,
+                                       alpha.data_ptr() - y0 * w * es, None, stream), "rank step (raster)")
+    self.last_counters = keep_n[lay.counters:lay.counters + 32].view(torch.int32)
+    return lay, keep_n, keep_k, image, alpha
+
+  def _loss_and_image_grad(self, image, loss_fn, backward):
+    image.requires_grad_(backward)
+    loss = loss_fn(image, self.px_rows)
+    if not backward:
+      return loss.detach(), None
+    g_image = None
+    if loss.requires_grad:
+      (g_image,) = torch.autograd.grad(loss, image, allow_unused=True)
+    if g_image is None:              # a loss that does not depend on this strip (empty strip): zeros join the collective
+      g_image = torch.zeros_like(image)
+    return loss.detach(), g_image.contiguous()
+
+  def check(self) -> dict:
+    """Host read (synchronises) of the device-side overflow flags of the LAST step."""
+    k, live, over = (self.last_counters[:3].tolist() if self.last_counters is not None else (0, 0, 0))
+    out = {"overlaps": k, "overlap_capacity": self.k_capacity, "overlap_overflow": bool(over)}
+    if self.flags is not None:
+      out["bucket_overflow"] = bool(int(self.flags[0].item()))
+    return out
+
+
+class StripStep(_RankStep):
+  """north_star partition: replicated gaussians, tile-row strips, reduce-scatter + all-gather of the 2D-boundary
+  gradients.  ``step(gaussians, camera, loss_fn)``: ``loss_fn(strip_image, (y0, y1))`` gets ONLY the strip's pixel
+  rows; afterwards ``.grad`` of the gaussians' leaf tensors holds the full gradient (identical on every rank)."""
+
+  def probe(self, gaussians: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.3):
+    """one synchronising dry run: fixes the overlap-list capacity of this rank's strip"""
+    from .mapper.tile_mapper import map_to_tiles_strip
+    from .perspective.projection import project_to_image
+    with torch.no_grad():
+      g2d, depths, _ = project_to_image(gaussians, camera_params, self.config)
+      o2p, _ = map_to_tiles_strip(g2d, depths, self.image_size, self.config, tile_rows=self.rows,
+                                  ndc_range=self.depth_range)
+    self.k_capacity = frame._round_capacity(o2p.shape[0] * slack)
+    return self.k_capacity
+
+  def step(self, gaussians: Gaussians3D, camera_params: CameraParams, loss_fn: Callable, use_sh: bool = True,
+           backward: bool = True):
+    assert self.k_capacity > 0, "StripStep.probe() first (fixes the overlap-list capacity)"
+    lib = _lib.load()
+    tensors = [t.detach().contiguous() for t in (*gaussians.shape_tensors(), gaussians.feature,
+                                                 camera_params.T_camera_world.reshape(4, 4), camera_params.projection.reshape(4))]
+    pos, lsc, rot, alog, feat, Tcw, proj = tensors
+    device, dtype, n = pos.device, pos.dtype, pos.shape[0]
+    f, degree = _feature_shape(feat, use_sh)
+    stream = _lib.current_stream(device)
+    timer = self.timer
+    timer.mark('start')
+    desc, _ = _desc(n, self.image_size, dtype, f, degree, self.config, self.depth_range, tile_rows=self.rows,
+                    capacity=self.k_capacity)
+    inputs = _lib.FrameInputsC(position=pos.data_ptr(), log_scaling=lsc.data_ptr(), rotation=rot.data_ptr(),
+                               alpha_logit=alog.data_ptr(), feature=feat.data_ptr(), T_camera_world=Tcw.data_ptr(),
+                               projection=proj.data_ptr(), points7=None, depth=None, colours=None)
+    lay, keep_n, keep_k, image, alpha = self._strip_forward(desc, inputs, device, dtype, f)
+    timer.mark('project_sh_map_raster')
+    loss, g_image = self._loss_and_image_grad(image, loss_fn, backward)
+    timer.mark('loss')
+    if not backward:
+      return image.detach(), loss
+
+    # raster backward of the strip -> (n, 7 + f) 2D-boundary gradients -> sum over the strips
+    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), 0))
+    width = 7 + f
+    rows = (n + self.world - 1) // self.world * self.world
+    gp = torch.empty((n, 7), dtype=dtype, device=device) if moments_path else torch.zeros((n, 7), dtype=dtype, device=device)
+    gc = torch.empty((n, f), dtype=dtype, device=device) if moments_path else torch.zeros((n, f), dtype=dtype, device=device)
+    gr = _lib.FrameGradsC()
+    y0 = self.px_rows[0]
+    row_bytes = y0 * self.image_size[0] * image.element_size()
+    gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
+    gr.stage = _lib.BACKWARD_RASTER
+    if moments_path:
+      gr.moments = frame._moments_buffer(device, n, False).data_ptr()
+    gr.grad_points7, gr.grad_colours = gp.data_ptr(), gc.data_ptr()
+    _lib.check(lib.ms_frame_backward(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), keep_k.data_ptr(),
+                                     ctypes.byref(gr), stream), "strip step (raster backward)")
+    timer.mark('raster_bwd')
+    if self.world > 1:
+      buf = torch.zeros((rows, width), dtype=dtype, device=device) if rows != n else torch.empty((rows, width), dtype=dtype, device=device)
+      buf[:n, :7] = gp
+      buf[:n, 7:] = gc
+      shard = torch.empty((rows // self.world, width), dtype=dtype, device=device)
+      dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
+      dist.all_gather_into_tensor(buf, shard, group=self.group)
+      gp, gc = buf[:n, :7].contiguous(), buf[:n, 7:].contiguous()
+      self.comm_bytes = {"reduce_scatter_plus_all_gather_buffer_bytes": rows * width * buf.element_size()}
+    timer.mark('reduce_scatter_all_gather')
+
+    need = [t.requires_grad for t in (*gaussians.shape_tensors(), gaussians.feature)]
+    grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
+    g2 = _lib.FrameGradsC()
+    g2.stage = _lib.BACKWARD_GAUSSIANS
+    g2.grad_points7, g2.grad_colours = gp.data_ptr(), gc.data_ptr()
+    g2.grad_position, g2.grad_log_scaling, g2.grad_rotation, g2.grad_alpha_logit = (_lib.ptr(t) for t in grads)
+    grad_feature = None
+    if need[4]:
+      if degree >= 0:
+        grad_feature = torch.empty_like(feat)
+        g2.grad_feature = grad_feature.data_ptr()
+      else:
+        grad_feature = gc
+    _lib.check(lib.ms_frame_backward(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), keep_k.data_ptr(),
+                                     ctypes.byref(g2), stream), "strip step (gaussian backward)")
+    timer.mark('gaussian_bwd')
+    for leaf, g in zip((*gaussians.shape_tensors(), gaussians.feature), (*grads, grad_feature)):
+      _accumulate(leaf, g)
+    return image.detach(), loss
+
+
+class ShardedStep(_RankStep):
+  """gaussians sharded by index, pixels by tile-row strip; fixed-capacity all-to-all both ways.
+
+  ``step(shard, camera, loss_fn)``: ``shard`` holds this rank's gaussians (``index_offset`` = global index of its
+  first one); afterwards ``.grad`` of its leaf tensors is the complete gradient of the summed loss."""
+
+  def __init__(self, *args, index_offset: int = 0, exchange=None, **kw):
+    super().__init__(*args, **kw)
+    self.index_offset = int(index_offset)
+    self.bucket_capacity = 0
+    self.exchange = exchange or (lambda recv, send: _exchange_all_to_all(recv, send, self.group))
+
+  def probe(self, shard: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.3, exchange=None):
+    """one synchronising dry run (a collective: every rank calls it): the largest per-destination bucket over all
+    ranks fixes the bucket capacity, this rank's strip fixes its overlap-list capacity.  ``exchange``: the
+    variable-size all-to-all of ``distributed.exchange_to_strips`` (default: RCCL)"""
+    from .distributed import exchange_to_strips, _all_to_all
+    from .mapper.tile_mapper import map_to_tiles_strip
+    from .perspective.projection import project_to_image
+    with torch.no_grad():
+      g2d, depths, idx = project_to_image(shard, camera_params, self.config)
+      feats = torch.zeros((g2d.shape[0], 3), dtype=g2d.dtype, device=g2d.device)
+      g2, f2, d, gid, plan = exchange_to_strips(g2d, feats, depths, self.image_size, self.config, self.bounds,
+                                                global_index=idx, index_offset=self.index_offset, group=self.group,
+                                                exchange=exchange or _all_to_all, return_plan=True)
+      biggest = torch.tensor([max(plan.send_counts) if plan.send_counts else 0], dtype=torch.int64)
+      if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.get_backend(self.group) != 'gloo':
+          biggest = biggest.to(g2d.device)
+        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
+      o2p, _ = map_to_tiles_strip(g2, d, self.image_size, self.config, tile_rows=self.rows, ndc_range=self.depth_range)
+    self.bucket_capacity = (int(int(biggest.item()) * slack) + 255) // 256 * 256
+    self.k_capacity = frame._round_capacity(o2p.shape[0] * slack)
+    return self.bucket_capacity, self.k_capacity
+
+  def step(self, shard: Gaussians3D, camera_params: CameraParams, loss_fn: Callable, use_sh: bool = True,
+           backward: bool = True):
+    assert self.k_capacity > 0 and self.bucket_capacity > 0, "ShardedStep.probe() first (fixes the capacities)"
+    lib = _lib.load()
+    tensors = [t.detach().contiguous() for t in (*shard.shape_tensors(), shard.feature,
+                                                 camera_params.T_camera_world.reshape(4, 4), camera_params.projection.reshape(4))]
+    pos, lsc, rot, alog, feat, Tcw, proj = tensors
+    device, dtype, n = pos.device, pos.dtype, pos.shape[0]
+    assert dtype == torch.float32, "ShardedStep: float32 (the routing kernels of csrc/strip_route.hip)"
+    f, degree = _feature_shape(feat, use_sh)
+    stream = _lib.current_stream(device)
+    world, cap = self.world, self.bucket_capacity
+    timer = self.timer
+    timer.mark('start')
+
+    # ---- per-gaussian stage on the shard (no compaction: culled gaussians carry depth 0 and are not routed) --------
+    desc_a, _ = _desc(n, self.image_size, dtype, f, degree, self.config, self.depth_range)
+    lay_a = _layout(desc_a)
+    keep_a = _block(lay_a.keep_n_bytes, device)
+    in_a = _lib.FrameInputsC(position=pos.data_ptr(), log_scaling=lsc.data_ptr(), rotation=rot.data_ptr(),
+                             alpha_logit=alog.data_ptr(), feature=feat.data_ptr(), T_camera_world=Tcw.data_ptr(),
+                             projection=proj.data_ptr(), points7=None, depth=None, colours=None)
+    _lib.check(lib.ms_frame_project(ctypes.byref(desc_a), ctypes.byref(in_a), keep_a.data_ptr(), stream), "sharded step (project)")
+    points7 = frame._view(keep_a, lay_a.points7, dtype, (n, 7))
+    depth = frame._view(keep_a, lay_a.depth, dtype, (n,))
+    colours = frame._view(keep_a, lay_a.colours, dtype, (n, f)) if degree >= 0 else feat
+    timer.mark('project_sh')
+
+    # ---- route into fixed buckets, exchange ------------------------------------------------------------------------
+    nb = lib.ms_strip_route_blocks(n)
+    route = torch.empty((max(n, 1),), dtype=torch.int32, device=device)
+    block_offsets = torch.empty((world * nb,), dtype=torch.int32, device=device)
+    send_counts = torch.empty((world,), dtype=torch.int64, device=device)
+    bounds_c = (ctypes.c_int32 * (world + 1))(*self.bounds)
+    _lib.check(lib.ms_strip_route_count(points7.data_ptr(), depth.data_ptr(), n, self.image_size[1], self.config.tile_size,
+                                        self.config.alpha_threshold, ctypes.cast(bounds_c, ctypes.c_void_p), world,
+                                        route.data_ptr(), block_offsets.data_ptr(), send_counts.data_ptr(), stream),
+               "sharded step (route)")
+    m = world * cap
+    width = 9 + f
+    send = torch.zeros((m, width), dtype=dtype, device=device)
+    send_index = torch.full((m,), -1, dtype=torch.int64, device=device)
+    if self.flags is None:
+      self.flags = torch.zeros((2,), dtype=torch.int32, device=device)
+    if n > 0:
+      _lib.check(lib.ms_strip_route_pack(points7.data_ptr(), colours.data_ptr(), depth.data_ptr(), None, f, n, world,
+                                         self.index_offset, route.data_ptr(), block_offsets.data_ptr(),
+                                         send_counts.data_ptr(), cap, self.flags.data_ptr(), send.data_ptr(),
+                                         send_index.data_ptr(), stream), "sharded step (pack)")
+    timer.mark('route_pack')
+    recv = torch.empty_like(send)
+    self.exchange(recv, send)
+    timer.mark('exchange_forward')
+
+    g2 = torch.empty((m, 7), dtype=dtype, device=device)
+    f2 = torch.empty((m, f), dtype=dtype, device=device)
+    d2 = torch.empty((m,), dtype=dtype, device=device)
+    ids = torch.empty((m,), dtype=torch.int64, device=device)
+    _lib.check(lib.ms_strip_unpack(recv.data_ptr(), m, f, g2.data_ptr(), f2.data_ptr(), d2.data_ptr(), ids.data_ptr(), stream),
+               "sharded step (unpack)")
+
+    # ---- this rank's strip from the received rows ------------------------------------------------------------------
+    desc_b, _ = _desc(m, self.image_size, dtype, f, -1, self.config, self.depth_range, tile_rows=self.rows,
+                      projected=True, capacity=self.k_capacity)
+    in_b = _lib.FrameInputsC(points7=g2.data_ptr(), depth=d2.data_ptr(), colours=f2.data_ptr())
+    lay_b, keep_b, keep_k, image, alpha = self._strip_forward(desc_b, in_b, device, dtype, f)
+    timer.mark('unpack_map_raster')
+    loss, g_image = self._loss_and_image_grad(image, loss_fn, backward)
+    timer.mark('loss')
+    es = image.element_size()
+    self.comm_bytes = {"all_to_all_forward_bytes": m * width * es, "all_to_all_backward_bytes": m * (7 + f) * es if backward else 0,
+                       "bucket_capacity_rows": cap, "off_chip_fraction": (world - 1) / world}
+    if not backward:
+      return image.detach(), loss
+
+    # ---- backward: strip raster -> gradients of the received rows -> home -> per-gaussian pass ---------------------
+    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc_b), 0))
+    gp = torch.empty((m, 7), dtype=dtype, device=device) if moments_path else torch.zeros((m, 7), dtype=dtype, device=device)
+    gc = torch.empty((m, f), dtype=dtype, device=device) if moments_path else torch.zeros((m, f), dtype=dtype, device=device)
+    gr = _lib.FrameGradsC()
+    row_bytes = self.px_rows[0] * self.image_size[0] * es
+    gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
+    gr.stage = _lib.BACKWARD_RASTER
+    if moments_path:
+      gr.moments = frame._moments_buffer(device, m, False).data_ptr()
+    gr.grad_points7, gr.grad_colours = gp.data_ptr(), gc.data_ptr()
+    _lib.check(lib.ms_frame_backward(ctypes.byref(desc_b), ctypes.byref(in_b), keep_b.data_ptr(), keep_k.data_ptr(),
+                                     ctypes.byref(gr), stream), "sharded step (raster backward)")
+    back_send = torch.cat([gp, gc], dim=1)
+    timer.mark('raster_bwd')
+    back = torch.empty_like(back_send)
+    self.exchange(back, back_send)
+    timer.mark('exchange_backward')
+
+    home_p = torch.zeros((n, 7), dtype=dtype, device=device)
+    home_c = torch.zeros((n, f), dtype=dtype, device=device)
+    if n > 0:
+      _lib.check(lib.ms_strip_return_grads(back.data_ptr(), send_index.data_ptr(), route.data_ptr(), f, m, home_p.data_ptr(),
+                                           home_c.data_ptr(), stream), "sharded step (return)")
+    need = [t.requires_grad for t in (*shard.shape_tensors(), shard.feature)]
+    grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
+    ga = _lib.FrameGradsC()
+    ga.stage = _lib.BACKWARD_GAUSSIANS
+    ga.grad_points7, ga.grad_colours = home_p.data_ptr(), home_c.data_ptr()
+    ga.grad_position, ga.grad_log_scaling, ga.grad_rotation, ga.grad_alpha_logit = (_lib.ptr(t) for t in grads)
+    grad_feature = None
+    if need[4]:
+      if degree >= 0:
+        grad_feature = torch.empty_like(feat)
+        ga.grad_feature = grad_feature.data_ptr()
+      else:
+        grad_feature = home_c
+    _lib.check(lib.ms_frame_backward(ctypes.byref(desc_a), ctypes.byref(in_a), keep_a.data_ptr(), None,
+                                     ctypes.byref(ga), stream), "sharded step (gaussian backward)")
+    timer.mark('return_gaussian_bwd')
+    for leaf, g in zip((*shard.shape_tensors(), shard.feature), (*grads, grad_feature)):
+      _accumulate(leaf, g)
+    return image.detach(), loss

@@ -2,7 +2,11 @@
 """Condense the rocprofv3 PMC passes of tools/pmc_collect.sh (summary.json) into the committed counter file that
 bench.py reads for `roofline.traffic` and `roofline.compute`:
 
-    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K [bwd.s fwd.s] > profiles/r02_raster_bwd_counters.json
+    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K [bwd.s fwd.s] > profiles/raster_bwd_counters.json
+
+The file carries `kernel_source_sha16` (bench.py::kernel_source_sha16 of the tree it is generated in — run it on the
+tree the counters were collected on) and the collection date: bench.py attaches the figures only to a binary built
+from byte-identical kernel sources.
 
 (bwd.s / fwd.s: hipcc -S output of raster_bwd_scan.hip / raster_fast.hip for the static instruction mix, tools/valu_mix.py)
 
@@ -77,7 +81,12 @@ if asm:
   mix_fwd = valu_mix(asm[1], f"_ZN2ms23raster_fwd_f32x3_kernelILi{tile}ELb0E")
 bwd = condense('raster_bwd_scan_kernel', (4 + 28 + 4 * f) * k + 8 * f * p + (28 + 4 * f) * k, mix_bwd)
 fwd = condense('raster_fwd_f32x3_kernel', (4 + 28 + 4 * f) * k + 4 * (f + 1) * p, mix_fwd)
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+import bench as _bench   # noqa: E402  (fingerprint of the kernel sources)
+import datetime          # noqa: E402
 result = {
+  "kernel_source_sha16": _bench.kernel_source_sha16(),
+  "collected": datetime.date.today().isoformat(),
   "_comment": "rocprofv3 --pmc passes (tools/pmc_collect.sh: one counter group per run, kernel trace only) of "
               f"tools/prof_raster.py {n} {size} {tile} on one MI355X, condensed by tools/pmc_to_profile.py. Values per launch.",
   "workload": {"n": n, "width": size, "height": size, "tile": tile, "K": k},
