@@ -49,13 +49,18 @@ def parse_args():
   p.add_argument('--no-stages', action='store_true')
   p.add_argument('--mode', choices=['auto', 'single', 'sharded', 'strips', 'both'], default='auto',
                  help='multi-GPU decomposition: sharded = gaussians by index + pixels by tile-row strip with an '
-                      'all-to-all of projected splats; strips = replicated gaussians + all-reduce (north_star); '
+                      'all-to-all of projected splats; strips = replicated gaussians + reduce-scatter / all-gather (north_star); '
                       'auto = both for N > 1 (value = the faster one)')
   p.add_argument('--forward-only', action='store_true')
   p.add_argument('--no-graph', action='store_true', help='skip the HIP-graph replay timing of the same step')
   p.add_argument('--graph-child', action='store_true', help=argparse.SUPPRESS)
   p.add_argument('--no-sweep', action='store_true', help='skip the tile 8 / 16 / 32 sweep (BASELINE.json configs[3])')
   p.add_argument('--even-strips', action='store_true', help='N > 1: equal tile rows per rank instead of overlap-balanced strips')
+  p.add_argument('--legacy-steps', action='store_true',
+                 help='N > 1: the round-2 rank steps of distributed.py (host reads of visible count / split sizes / overlap '
+                      'total) instead of the sync-free steps of sharded.py')
+  p.add_argument('--rank-graph', action='store_true',
+                 help='N > 1: replay the rank step from a HIP graph (RCCL collectives captured with it); off by default')
   p.add_argument('--launcher', action='store_true',
                  help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
   return p.parse_args()
@@ -261,10 +266,29 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
   leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
   comm = {}
 
+  static = None
+  if mode in ('sharded', 'strips') and not args.legacy_steps:
+    # sync-free rank steps (taichi_splatting_amd/sharded.py): capacities from one synchronising dry run, here, outside
+    # the timed region (like the strip bounds)
+    from taichi_splatting_amd import sharded
+    from taichi_splatting_amd.distributed import strip_bounds
+    ts = cfg.tile_size
+    tiles_high = (cam.image_size[1] + ts - 1) // ts
+    use_bounds = bounds if bounds is not None else strip_bounds(tiles_high, world)
+    cls = sharded.ShardedStep if mode == 'sharded' else sharded.StripStep
+    kw = dict(index_offset=shard_begin) if mode == 'sharded' else {}
+    static = cls(cam.image_size, cfg, cam.depth_range, rank, world, use_bounds, **kw)
+    with torch.no_grad():
+      caps = static.probe(g, cam, True)
+    log(f"[{mode}] sync-free step, capacities {caps}")
+  loss_fn = lambda img, rows: img.sum()
+
   def step():
     for t in leaves:
       t.grad = None
-    if mode == 'sharded':
+    if static is not None:
+      static.step(g, cam, loss_fn, use_sh=True, backward=not args.forward_only)
+    elif mode == 'sharded':
       render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
                           backward=not args.forward_only, index_offset=shard_begin, comm_stats=comm, bounds=bounds)
     elif mode == 'strips':
@@ -285,18 +309,40 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
     step()
   torch.cuda.synchronize()
   log(f"[{mode}] {args.warmup} warmup steps done")
+  run = step
+  if static is not None and args.rank_graph:
+    from taichi_splatting_amd import frame as frame_mod0
+    graph = frame_mod0.FrameGraph(step, warmup=1)
+    run = graph.replay
+    comm['hip_graph'] = True
 
   from taichi_splatting_amd import frame as frame_mod
   barrier()
   syncs0 = frame_mod.host_syncs + frame_mod.point_syncs
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    step()
+    run()
   torch.cuda.synchronize()
   mine = time.perf_counter() - t0            # this rank's own time (before waiting for the slowest)
   comm['host_syncs_per_step'] = (frame_mod.host_syncs + frame_mod.point_syncs - syncs0) / max(args.steps, 1)
   barrier()
   elapsed = time.perf_counter() - t0
+  if static is not None:
+    # per-stage GPU time of this rank (HIP events at the stage boundaries, a few extra steps after the timed region)
+    # and the overflow flags of the fixed-capacity buffers
+    from taichi_splatting_amd import sharded
+    comm.update(static.comm_bytes)
+    status = static.check()
+    if status.get('overlap_overflow') or status.get('bucket_overflow'):
+      raise RuntimeError(f"[{mode}] rank {rank}: a fixed-capacity buffer overflowed ({status}); the timed frames are invalid")
+    static.timer = sharded.StageTimer(True)
+    for _ in range(5):
+      step()
+      torch.cuda.synchronize()
+      static.timer.end_step()
+    comm['stage_ms'] = static.timer.mean_ms()
+    static.timer = sharded.StageTimer(False)
+    barrier()
   per_rank = [mine]
   if distributed:
     t = torch.tensor([elapsed, mine], dtype=torch.float64, device=device)
@@ -304,6 +350,11 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
     dist.all_gather(all_t, t)
     elapsed = max(float(x[0]) for x in all_t)
     per_rank = [float(x[1]) for x in all_t]
+  if distributed and static is not None:
+    # every rank's stage breakdown on rank 0 (compute / exchange / host can be told apart without rerunning)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, comm.get('stage_ms'))
+    comm['stage_ms_per_rank'] = gathered
   g.requires_grad_(False)
   for t in leaves:
     t.grad = None
@@ -331,6 +382,19 @@ def main():
     dist.init_process_group('nccl')
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
+  job = {"world_size": world, "backend": None, "devices": [torch.cuda.get_device_name(device)]}
+  if distributed:
+    # what ran, from the process group itself: world size, every rank's device, the RCCL build
+    import torch.distributed as dist
+    names = [None] * world
+    dist.all_gather_object(names, f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(device)}")
+    try:
+      rccl = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+      rccl = 'unknown'
+    job = {"world_size": dist.get_world_size(), "backend": f"{dist.get_backend()} (RCCL {rccl})", "devices": names}
+    print(f"[bench] rank {rank}/{dist.get_world_size()} on cuda:{local_rank} {torch.cuda.get_device_name(device)}, "
+          f"backend {dist.get_backend()}, RCCL {rccl}", file=sys.stderr, flush=True)
 
   from taichi_splatting_amd import RasterConfig, _lib
   _lib.load()
@@ -356,7 +420,7 @@ def main():
                   "host_syncs_per_step": comm.pop('host_syncs_per_step', None),
                   "strips": "even tile rows" if args.even_strips or world == 1 else "overlap-balanced",
                   "rank_ms_per_step": [round(t / args.steps * 1e3, 3) for t in per_rank],
-                  "rank0_exchange_bytes_per_step": comm or None}
+                  "rank0_step": comm or None}
     if mode != modes[-1]:
       del g
       torch.cuda.empty_cache()
@@ -383,8 +447,11 @@ def main():
                                "strips": f"replicated gaussians, tile-row strips x{world}, all-reduce of 2D-boundary grads"}[mode]},
   }
   result["host_syncs_per_step"] = runs[mode]["host_syncs_per_step"]
-  if world > 1:
+  result["job"] = job
+  if world > 1 or mode != 'single':
     result["modes"] = runs
+    result["host_sync_note"] = ("sync-free rank steps (taichi_splatting_amd/sharded.py): fixed-capacity buckets / overlap "
+                                "lists, counts stay on the device" if not args.legacy_steps else "round-2 rank steps")
   else:
     result["host_sync_note"] = ("the one wait per frame is on the overlap total, AFTER the whole forward pass is "
                                 "enqueued (the GPU never idles for it); 0 inside a captured HIP graph")

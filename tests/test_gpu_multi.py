@@ -25,8 +25,19 @@ def run_bench(*extra):
 def test_launcher_world_size_one_uses_rccl():
   """one rank under torch.distributed.run: init_process_group('nccl'), barrier and all_gather on the device"""
   out = run_bench('--gpus', '1', '--launcher', '--mode', 'both')
-  assert out['n_gpus'] == 1 and set(out['modes']) == {'strips', 'sharded'} if 'modes' in out else out['n_gpus'] == 1
-  assert out['value'] > 0
+  assert out['n_gpus'] == 1 and out['value'] > 0
+  assert out['job']['world_size'] == 1 and 'nccl' in out['job']['backend'] and len(out['job']['devices']) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('extra', [(), ('--rank-graph',), ('--legacy-steps',)])
+def test_rank_steps_on_one_rank_report_stages(extra):
+  """the N > 1 code path of bench.py with world size 1 (RCCL collectives on one device): sync-free steps, eagerly and
+  replayed from a HIP graph, and the round-2 steps"""
+  out = run_bench('--gpus', '1', '--launcher', '--mode', 'sharded', '--no-graph', '--no-sweep', *extra)
+  assert out['config']['mode'] == 'sharded' and out['value'] > 0
+  if '--legacy-steps' not in extra:
+    assert out['host_syncs_per_step'] == 0
 
 
 @pytest.mark.gpu
@@ -36,5 +47,5 @@ def test_two_gpus_both_modes():
   assert out['n_gpus'] == 2
   assert set(out['modes']) == {'strips', 'sharded'}
   for m in out['modes'].values():
-    assert len(m['rank_ms_per_step']) == 2 and m['value'] > 0 and m['rank0_exchange_bytes_per_step']
+    assert len(m['rank_ms_per_step']) == 2 and m['value'] > 0 and m['rank0_step']['stage_ms_per_rank'] and len(m['rank0_step']['stage_ms_per_rank']) == 2
   assert out['config']['mode'] in out['modes']

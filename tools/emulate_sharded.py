@@ -68,7 +68,12 @@ def main():
   p.add_argument('--warmup', type=int, default=2)
   p.add_argument('--cprofile', action='store_true', help='host-side profile of the timed steps (stderr)')
   p.add_argument('--ranks', type=str, default='', help='comma separated ranks to time (default: all)')
+  p.add_argument('--static', action='store_true',
+                 help='the sync-free step of taichi_splatting_amd/sharded.py (ShardedStep: fixed buckets, frame executor), '
+                      'timed eagerly and as a HIP-graph replay')
   args = p.parse_args()
+  if args.static:
+    return main_static(args)
   import bench
   from taichi_splatting_amd import RasterConfig, render_gaussians
   from taichi_splatting_amd.distributed import render_sharded_step, shard_range
@@ -136,6 +141,119 @@ def main():
   out = {"world": W, "n": args.n, "image": [args.size, args.height or args.size], "single_gpu_ms": round(t_single, 3),
          "per_rank_ms": per_rank, "max_rank_ms": max(per_rank), "recv_splats": recv,
          "compute_only_speedup": round(t_single / max(per_rank), 2),
+         "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
+  print(json.dumps(out))
+
+
+def main_static(args):
+  """ShardedStep per rank on one GPU: the forward all-to-all delivers the rows recorded from all W shards, the
+  reverse one a buffer of the right size (its values do not matter for the time)."""
+  import bench
+  from taichi_splatting_amd import RasterConfig, frame, render_gaussians, sharded
+  from taichi_splatting_amd.distributed import overlap_balanced_bounds, shard_range
+  from taichi_splatting_amd.perspective.projection import project_to_image
+  dev = torch.device('cuda', 0)
+  cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  g, cam = bench.make_scene(args, dev)
+  W = args.world
+  size = cam.image_size
+  loss_fn = lambda img, rows: img.sum()
+
+  def timed(fn, steps=None):
+    steps = steps or max(args.steps, 20)
+    for _ in range(args.warmup):
+      fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+  full = g.clone().requires_grad_(True)
+  full_leaves = (full.position, full.log_scaling, full.rotation, full.alpha_logit, full.feature)
+
+  def single():
+    for t in full_leaves:
+      t.grad = None
+    render_gaussians(full, cam, cfg, use_sh=True).image.sum().backward()
+  t_single = timed(single)
+  with torch.no_grad():
+    bounds = overlap_balanced_bounds(project_to_image(g, cam, cfg)[0], size, cfg, W)
+  del full
+
+  shards, steps_ = [], []
+  recorded = {}
+  for r in range(W):
+    b, e = shard_range(args.n, W, r)
+    shard = g[b:e].clone().contiguous().requires_grad_(True)
+    shards.append(shard)
+    st = sharded.ShardedStep(size, cfg, cam.depth_range, r, W, bounds, index_offset=b)
+    steps_.append(st)
+  # capacities: the probe is a collective in a real job; here: bucket = largest over ranks, overlaps per strip
+  from taichi_splatting_amd.distributed import exchange_to_strips
+  from taichi_splatting_amd.mapper.tile_mapper import map_to_tiles_strip
+  biggest, rows_for = 0, {r: [] for r in range(W)}
+  with torch.no_grad():
+    for r in range(W):
+      g2d, depths, idx = project_to_image(shards[r], cam, cfg)
+      feats = torch.zeros((g2d.shape[0], 3), device=dev)
+      loop = lambda send, sc, rc, group: send.clone()
+      _, _, _, _, plan = exchange_to_strips(g2d, feats, depths, size, cfg, bounds, global_index=idx,
+                                            index_offset=steps_[r].index_offset, exchange=loop, return_plan=True)
+      biggest = max(biggest, max(plan.send_counts))
+  cap = (int(biggest * 1.3) + 255) // 256 * 256
+  for st in steps_:
+    st.bucket_capacity = cap
+    st.k_capacity = 1 << 26             # generous for the recording pass; fixed per rank below
+  # recording pass: every rank's send buffer
+  for r in range(W):
+    def rec(recv, send, r=r):
+      if send.shape[1] == 12:
+        recorded[r] = send.clone()
+      recv.copy_(send)
+    steps_[r].exchange = rec
+    with torch.no_grad():
+      steps_[r].step(shards[r], cam, loss_fn, use_sh=True, backward=False)
+  per_rank, per_rank_graph, stages = [], [], []
+  for r in ([int(x) for x in args.ranks.split(',')] if args.ranks else range(W)):
+    st, shard = steps_[r], shards[r]
+    recv_rows = torch.cat([recorded[s][r * cap:(r + 1) * cap] for s in range(W)]).contiguous()
+
+    def ex(recv, send):
+      if send.shape[1] == 12:
+        recv.copy_(recv_rows)
+      else:
+        recv.copy_(send)
+    st.exchange = ex
+    with torch.no_grad():
+      st.step(shard, cam, loss_fn, use_sh=True, backward=False)
+    st.k_capacity = frame._round_capacity(int(st.check()['overlaps']) * 1.3)
+    leaves = (shard.position, shard.log_scaling, shard.rotation, shard.alpha_logit, shard.feature)
+
+    def step():
+      for t in leaves:
+        t.grad = None
+      st.step(shard, cam, loss_fn, use_sh=True)
+    per_rank.append(round(timed(step), 3))
+    st.timer = sharded.StageTimer(True)
+    for _ in range(5):
+      step(); torch.cuda.synchronize(); st.timer.end_step()
+    stages.append(st.timer.mean_ms())
+    st.timer = sharded.StageTimer(False)
+    graph = frame.FrameGraph(step, warmup=1)
+    per_rank_graph.append(round(timed(graph.replay), 3))
+    assert not st.check()['overlap_overflow'] and not st.check()['bucket_overflow']
+    del graph
+    for t in leaves:
+      t.grad = None
+  out = {"world": W, "n": args.n, "image": list(size), "step": "sharded.ShardedStep (sync-free, fixed buckets)",
+         "single_gpu_ms": round(t_single, 3), "bounds": bounds, "bucket_capacity_rows": cap,
+         "per_rank_ms_eager": per_rank, "per_rank_ms_graph": per_rank_graph,
+         "max_rank_ms_eager": max(per_rank), "max_rank_ms_graph": max(per_rank_graph),
+         "compute_only_speedup_eager": round(t_single / max(per_rank), 2),
+         "compute_only_speedup_graph": round(t_single / max(per_rank_graph), 2),
+         "stage_ms_rank0": stages[0],
          "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
   print(json.dumps(out))
 
