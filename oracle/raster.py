@@ -239,6 +239,35 @@ def gate_margin(points, ranges, o2p, image_size, cfg, tile_rows: Optional[Tuple[
   return margin
 
 
+def near_gate(points, ranges, o2p, image_size, cfg, eps: float):
+  """Where can a float32 implementation legitimately differ?  Returns (pixel_flag (H, W) bool: some (pixel, splat)
+  pair of the pixel's tile list has alpha_pt * g within ``eps`` (relative) of the blend gate; splat_flag (V,) bool:
+  the splat contributes — alpha above half the threshold — to such a pixel).  One flipped gate moves its pixel and,
+  through T and the remaining colour, the gradient of EVERY splat that contributes to that pixel: tests on unfiltered
+  scenes require that each deviation beyond the tolerance is explained by these flags (and count the unexplained)."""
+  w, h = image_size
+  ts = cfg.tile_size
+  tiles_wide, tiles_high = _tiles(image_size, ts)
+  pixel_flag = torch.zeros((h, w), dtype=torch.bool)
+  splat_flag = torch.zeros((points.shape[0],), dtype=torch.bool)
+  ranges = ranges.reshape(-1, 2)
+  for tile_id in range(tiles_wide * tiles_high):
+    start, end = int(ranges[tile_id, 0]), int(ranges[tile_id, 1])
+    if end <= start:
+      continue
+    px, py, inb, pix = _tile_pixels(tile_id, tiles_wide, ts, w, h, points.dtype)
+    if not bool(inb.any()):
+      continue
+    ids = o2p[start:end].long()
+    g = points[ids]
+    a_raw = g[None, :, 6] * pdf(pix[inb], g, cfg.antialias)                  # (pixels, splats)
+    flagged = ((a_raw / cfg.alpha_threshold - 1).abs() < eps).any(dim=1)
+    pixel_flag[py[inb].long(), px[inb].long()] = flagged
+    touched = ((a_raw > 0.5 * cfg.alpha_threshold) & flagged[:, None]).any(dim=0)
+    splat_flag[ids[touched]] = True
+  return pixel_flag, splat_flag
+
+
 def backward(points, feats, ranges, o2p, image, grad_image, image_size, cfg,
              tile_rows: Optional[Tuple[int, int]] = None):
   """Literal restatement of backward.py:97-224.  Returns grad_points (V,7), grad_feats (V,F),

@@ -18,7 +18,7 @@ from . import optim
 from .perspective import CameraParams
 from .taichi_queue import TaichiQueue, taichi_queue, queued
 
-__version__ = '0.1.0'
+__version__ = '0.3.0'
 
 __all__ = [
   'render_gaussians', 'Rendering',
@@ -40,7 +40,9 @@ def install_as_taichi_splatting():
               'perspective', 'perspective.params',
               'perspective.projection', 'mapper', 'mapper.tile_mapper', 'rasterizer',
               'rasterizer.function', 'cuda_lib', 'misc', 'misc.renderer2d', 'misc.morton_sort', 'optim', 'optim.fractional',
-              'optim.visibility_aware', 'optim.parameter_class', 'benchmarks', 'examples',
+              'optim.visibility_aware', 'optim.parameter_class', 'optim.util', 'benchmarks', 'benchmarks.util',
+              'benchmarks.bench_projection', 'benchmarks.bench_rasterizer', 'benchmarks.bench_tilemapper',
+              'benchmarks.bench_sh', 'examples',
               'examples.fit_image_gaussians'):
     mod = importlib.import_module(f'{__name__}.{sub}')
     sys.modules.setdefault(f'taichi_splatting.{sub}', mod)

@@ -498,12 +498,16 @@ def overlap_balanced_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, in
   gs = torch.sqrt(2.0 * torch.log(alpha / config.alpha_threshold))
   ex = torch.sqrt((ax * sx * gs) ** 2 + (ay * sy * gs) ** 2)
   ey = torch.sqrt((ay * sx * gs) ** 2 + (ax * sy * gs) ** 2)
-  ok = torch.isfinite(ex) & torch.isfinite(ey)
+  ok = torch.isfinite(ex) & torch.isfinite(ey) & torch.isfinite(mx) & torch.isfinite(my)
   cols = (torch.ceil((mx + ex) / ts).clamp(0, tiles_wide) - torch.floor((mx - ex) / ts).clamp(0, tiles_wide)).clamp(min=1)
   lo = torch.floor((my - ey) / ts).clamp(0, tiles_high - 1)
   hi = torch.ceil((my + ey) / ts).clamp(1, tiles_high)
   hi = torch.maximum(hi, lo + 1)
+  # rows the mapper culls (alpha below the threshold, NaN / inf extents) weigh nothing AND must not index: their
+  # lo / hi are NaN, which converts to INT64_MIN
   weight = torch.where(ok, cols, torch.zeros_like(cols))
+  lo = torch.where(ok, lo, torch.zeros_like(lo))
+  hi = torch.where(ok, hi, torch.ones_like(hi))
   # difference array: +cols at lo, -cols at hi, then a prefix sum gives overlaps per tile row
   diff = torch.zeros((tiles_high + 1,), dtype=torch.float32, device=p.device)
   diff.index_add_(0, lo.to(torch.int64), weight.float())

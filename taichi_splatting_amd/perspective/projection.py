@@ -18,20 +18,12 @@ from ..data_types import Gaussians3D, RasterConfig
 from .params import CameraParams
 
 
-_all_indexes = {}
-
-
 def _identity_indexes(n: int, device: torch.device) -> torch.Tensor:
-  """arange(n) int64 for the "every gaussian is visible" case, kept per (device, n): it is built right after the
-  host synchronisation on the visible count, when the launch queue is empty and every extra launch is exposed
-  latency (48 MB of writes at 6 M gaussians).  Callers treat ``indexes`` as read-only (it is marked
-  non-differentiable and only ever indexed with)."""
-  key = (device.type, device.index, n)
-  cached = _all_indexes.get(key)
-  if cached is None:
-    _all_indexes.clear()                  # one scene at a time: do not hoard 8 B per gaussian per size
-    cached = _all_indexes[key] = torch.arange(n, dtype=torch.int64, device=device)
-  return cached
+  """arange(n) int64 for the "every gaussian is visible" case: one shared, read-only tensor per (device, n), built
+  outside inference mode so that an evaluation render under ``torch.inference_mode()`` cannot hand an inference
+  tensor to later training frames (``frame.identity_indexes``)."""
+  from ..frame import identity_indexes
+  return identity_indexes(n, device)
 
 
 def _project_forward(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,

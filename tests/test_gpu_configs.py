@@ -82,20 +82,22 @@ def oracle_leaf_grads(g, cam, cfg, grad_points, grad_feats, dtype):
   return idx, [x.grad.double() for x in leaves]
 
 
-def gate_stable(g, cam, cfg, rel_margin=3e-3):
-  """Drop the gaussians whose projected splat has a pixel within ``rel_margin`` of the blend gate, judged on BOTH
-  the float64 oracle's splats and the float32 splats the kernels produce (the float32 projection moves alpha * g
-  by ~1e-6 relative in general and by up to ~1e-3 for nearly isotropic splats, whose axis is ill-conditioned)."""
-  o = oracle_frame(g, cam, cfg, None)
+PROJECTION_SHIFT = 3e-3     # the float32 projection moves alpha * g by ~1e-6 relative in general and by up to ~1e-3
+                            # for nearly isotropic splats, whose axis is ill-conditioned
+
+
+def gate_stable(g, cam, cfg, rel_margin=1e-4):
+  """Drop the gaussians whose splat — the float32 splat the KERNELS produce — has a pixel within ``rel_margin`` of the
+  blend gate: the rasterizer is then compared strictly (1e-4, every pixel and gradient row) on its own inputs.  The
+  end-to-end comparison with the float64 pipeline additionally sees the float32 projection's shift of alpha * g
+  (PROJECTION_SHIFT); deviations there must be explained pixel by pixel (oracle.raster.near_gate), not filtered."""
   keep = torch.ones(g.position.shape[0], dtype=torch.bool)
-  margin = orast.gate_margin(o['points'], o['ranges'], o['o2p'], cam.image_size, cfg)
-  keep[o['idx'][margin < rel_margin]] = False
   with torch.no_grad():
     p32, d32, idx32 = project_to_image(g.to(DEV), cam.to(device=DEV), cfg)
     o2p32, ranges32 = map_to_tiles(p32, ndc_depth(d32, cam.near_plane, cam.far_plane), cam.image_size, cfg)
   margin32 = orast.gate_margin(p32.cpu().double(), ranges32.cpu(), o2p32.cpu(), cam.image_size, cfg)
   keep[idx32.cpu()[margin32 < rel_margin]] = False
-  assert keep.float().mean() > 0.6
+  assert keep.float().mean() > 0.9          # a 1e-4 margin removes a few per cent of the gaussians at most
   return g[keep]
 
 
@@ -118,10 +120,14 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   assert torch.equal(r.points.idx.cpu(), want['idx'])                       # same visible set
   # whole pipeline against the float64 oracle pipeline, every pixel: the float32 projection moves the splat
   # parameters by ~1e-6 relative (the axis of a nearly isotropic splat by up to ~1e-3 rad), which shows up as up to
-  # ~1e-4 in a pixel; the rasterizer itself is held to 1e-4 on its own inputs below
-  err = (r.image.detach().cpu().double() - want['image']).abs()
-  assert err.max() < 2e-4, (name, err.max().item())
-  assert (r.image_weight.detach().cpu().double() - want['alpha']).abs().max() < 2e-4
+  # ~1e-4 in a pixel — or as a flipped gate where the float64 splat has a pair within PROJECTION_SHIFT of the
+  # threshold.  Every pixel beyond 2e-4 must be such a pixel (count of unexplained ones: zero); the rasterizer
+  # itself is held to 1e-4 on its own inputs below
+  err = (r.image.detach().cpu().double() - want['image']).abs().max(-1).values
+  err = torch.maximum(err, (r.image_weight.detach().cpu().double() - want['alpha']).abs())
+  pixel_flag, _ = orast.near_gate(want['points'].detach(), want['ranges'], want['o2p'], size, cfg, PROJECTION_SHIFT)
+  unexplained = (err > 2e-4) & ~pixel_flag
+  assert int(unexplained.sum()) == 0, (name, int(unexplained.sum()), float(err[unexplained].max()))
   r.points.gaussians2d.retain_grad()
   r.points.features.retain_grad()
   (r.image * G.to(DEV).float()).sum().backward()

@@ -113,21 +113,30 @@ def test_projection_f32_backward_vs_oracle(seed):
   g = random_3d_gaussians(n=n, camera_params=camera, margin=0.5, scale_factor=0.1 if seed % 2 else 1.0)
   inputs = [t.float() for t in g.shape_tensors()] + [camera.T_camera_world.float(), camera.projection.float()]
 
-  def run(f, args, gp=None, gd=None):
-    args = [a.detach().clone().requires_grad_(True) for a in args]
-    points, depth, idx = f(*args)
-    if gp is None:
-      torch.manual_seed(100 + seed)
-      gp, gd = torch.randn(points.shape, dtype=torch.float64), torch.randn(depth.shape, dtype=torch.float64)
-    torch.autograd.backward([points, depth], [gp.to(points), gd.to(depth)])
-    return (points.detach(), depth.detach(), idx), [a.grad for a in args], gp, gd
   f_o = lambda *a: oproj.apply(*a, camera.image_size, camera.depth_range, blur_cov=0.3)
   f_h = lambda *a: hip_proj.apply(*a, camera.image_size, camera.depth_range, blur_cov=0.3)
-  o64, g64, gp, gd = run(f_o, [t.double() for t in inputs])
-  o32, g32, _, _ = run(f_o, inputs, gp, gd)
-  if not torch.equal(o32[2], o64[2]):
-    pytest.skip("a culling decision flips between float32 and float64 for this seed")
-  oh, gh, _, _ = run(f_h, [t.to(DEV) for t in inputs], gp.to(DEV), gd.to(DEV))
+  in64, in32, in_h = [t.double() for t in inputs], inputs, [t.to(DEV) for t in inputs]
+  # a culling decision may flip between float32 and float64 for a gaussian on the edge of the view: the upstream
+  # gradients are drawn per GAUSSIAN and zeroed outside the set all three evaluations agree on, so that every
+  # gaussian (and every camera sum) is compared on common ground instead of skipping the seed
+  with torch.no_grad():
+    sets = [set(f(*a)[2].cpu().tolist()) for f, a in ((f_o, in64), (f_o, in32), (f_h, in_h))]
+  common = torch.zeros(n, dtype=torch.bool)
+  common[sorted(sets[0] & sets[1] & sets[2])] = True
+  assert len(sets[0] ^ sets[2]) <= 4 and int(common.sum()) >= len(sets[0]) - 4      # flips are edge cases, not the rule
+  torch.manual_seed(100 + seed)
+  gp_all = torch.randn((n, 7), dtype=torch.float64) * common[:, None]
+  gd_all = torch.randn((n, 1), dtype=torch.float64) * common[:, None]
+
+  def run(f, args):
+    args = [a.detach().clone().requires_grad_(True) for a in args]
+    points, depth, idx = f(*args)
+    torch.autograd.backward([points, depth], [gp_all.to(points)[idx], gd_all.to(depth)[idx]])
+    keep = common.to(idx.device)[idx]
+    return (points.detach()[keep], depth.detach()[keep], idx[keep]), [a.grad for a in args]
+  o64, g64 = run(f_o, in64)
+  o32, g32 = run(f_o, in32)
+  oh, gh = run(f_h, in_h)
   assert torch.equal(oh[2].cpu(), o64[2])
   # forward: mean, sigma, alpha, depth to 1e-4 relative; the axis of a near-isotropic splat is ill-conditioned
   assert torch.allclose(oh[0].cpu()[:, [0, 1, 4, 5, 6]].double(), o64[0][:, [0, 1, 4, 5, 6]], rtol=1e-4, atol=1e-3)
