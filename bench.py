@@ -379,7 +379,8 @@ def main():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl')
+    import datetime
+    dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=300))     # a hung collective fails the run, it does not stall it
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
   job = {"world_size": world, "backend": None, "devices": [torch.cuda.get_device_name(device)]}
@@ -411,9 +412,15 @@ def main():
   log("scene on device")
   use_sh = True
 
-  runs = {}
+  runs, failed = {}, {}
   for mode in modes:
-    elapsed, per_rank, comm, g = run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed)
+    try:
+      elapsed, per_rank, comm, g = run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed)
+    except Exception as e:          # one decomposition failing must not lose the other's number
+      import traceback
+      failed[mode] = repr(e)
+      print(f"[bench] rank {rank}: mode {mode} failed: {e!r}\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+      continue
     ms = elapsed / args.steps * 1e3
     log(f"[{mode}] timed {args.steps} steps: {ms:.3f} ms/step")
     runs[mode] = {"ms_per_step": round(ms, 3), "value": round(args.n / (ms * 1e-3) / 1e6, 2),
@@ -424,6 +431,8 @@ def main():
     if mode != modes[-1]:
       del g
       torch.cuda.empty_cache()
+  if not runs:
+    raise SystemExit(f"bench.py: every mode failed: {failed}")
   mode = min(runs, key=lambda m: runs[m]["ms_per_step"])
   ms_per_step = runs[mode]["ms_per_step"]
   value = runs[mode]["value"]
@@ -448,6 +457,8 @@ def main():
   }
   result["host_syncs_per_step"] = runs[mode]["host_syncs_per_step"]
   result["job"] = job
+  if failed:
+    result["failed_modes"] = failed
   if world > 1 or mode != 'single':
     result["modes"] = runs
     result["host_sync_note"] = ("sync-free rank steps (taichi_splatting_amd/sharded.py): fixed-capacity buckets / overlap "
