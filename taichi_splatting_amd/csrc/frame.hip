@@ -116,10 +116,9 @@ f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_
 }
 
 static bool frame_uses_moments(const ms_frame_desc* d, int deterministic) {
-  // raster_bwd_scan.hip: float32 RGB, plain pdf; tile 32 only in the deterministic mode (the pixel-per-lane kernel
-  // is as fast there, rasterizer/function.py::_use_moments_backward)
-  if (d->dtype != MS_F32 || d->f != 3 || d->raster.antialias || !d->raster.use_alpha_blending) return false;
-  return d->raster.tile_size <= 16 || deterministic != 0;
+  // raster_bwd_scan.hip: float32 RGB, plain pdf, every tile size (rasterizer/function.py::_use_moments_backward)
+  (void)deterministic;
+  return d->dtype == MS_F32 && d->f == 3 && !d->raster.antialias && d->raster.use_alpha_blending;
 }
 
 }  // namespace ms

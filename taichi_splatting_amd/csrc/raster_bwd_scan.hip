@@ -32,6 +32,8 @@
 //
 // VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~46 instructions / (lanes filled) ~= 16 wave
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
+#include <stdlib.h>
+
 #include "raster_common.h"
 #include "frame_internal.h"
 
@@ -42,6 +44,13 @@
 #endif
 #ifndef MS_SCAN_ABLATE
 #define MS_SCAN_ABLATE 0
+#endif
+// tile 32 (one 1024-thread workgroup per tile): staged splats per batch / accumulator rows per wave
+#ifndef MS_T32_BATCH
+#define MS_T32_BATCH 896
+#endif
+#ifndef MS_T32_CAP
+#define MS_T32_CAP 128
 #endif
 
 namespace ms {
@@ -155,18 +164,22 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // Splats staged per batch (shared by the tile's waves).  A tile's list is cut into EQUAL batches of about
   // BATCH_TARGET (see the batch loop): with fixed 256-splat batches config D's ~779 splats per tile end in an
   // 11-splat batch whose chunks run all 16 pixel steps for a couple of lanes — a quarter of all chunks.
-  constexpr int BATCH = TS == 8 ? 128 : (TS == 16 && !HEUR) ? 268 : 256;
-  constexpr int BATCH_TARGET = TS == 8 ? 112 : 256;
+  // TS == 32 (one 1024-thread workgroup per 32 x 32 tile, 16 waves): an 8x8 patch sees ~1/8 of the tile's splats, so
+  // the batch is 896 splats for the per-wave lists to be as long as at tile 16 (~115 patch hits); 43 KB of records +
+  // 16 x 6.6 KB per-wave state = 152 of the CU's 160 KB LDS: one workgroup per CU = the same 4 waves per SIMD
+  constexpr int BATCH = TS == 8 ? 128 : TS == 32 ? MS_T32_BATCH : (TS == 16 && !HEUR) ? 268 : 256;
+  constexpr int BATCH_TARGET = TS == 8 ? 112 : TS == 32 ? MS_T32_BATCH - 64 : 256;
   // Patch hits a wave takes on per pass (>= 64: a pass always advances) = rows of its accumulator.  A wave whose
   // patch list overflows runs the rest of the batch as a second pass with nearly empty chunks, so at tile 16 the
   // 40 KB a workgroup may use (four per CU) go to CAP first and to the staging batch second (config D, ms;
   // a batch of ~260 splats puts ~100 on an 8x8 patch):
   //   BATCH / CAP   320 / 112: 1.50    268 / 128: 1.43    256 / 132: 1.51    (3.27 / 3.04 / 3.04 at 4096^2)
   //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
-  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : 128;
+  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : 128;
   constexpr int NACC = HEUR ? 11 : 9;
-  constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and 256 + t)
-  constexpr int SLOTS_B = PIPELINED ? BATCH - 256 : 0;     // second slot of the first SLOTS_B threads
+  constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and PRIMARY + t)
+  constexpr int PRIMARY = THREADS < BATCH ? THREADS : BATCH;      // slots filled by "thread t stages slot t"
+  constexpr int SLOTS_B = PIPELINED ? BATCH - PRIMARY : 0;  // second slot of the first SLOTS_B threads
   static_assert(SLOTS_B >= 0 && SLOTS_B <= 64, "second staging slot: first wave only");
   // tile 16: 12.6 KB records + 1 KB ids + 4 x (4.5 KB accumulators + 0.75 KB lists + 1.25 KB pixels) = 39.9 KB: four
   // workgroups per CU
@@ -234,8 +247,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     if (t < bsz && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
     if (t < bsz && start + bsz + t < end) next_id = o2p[start + bsz + t];
     if (t < SLOTS_B) {
-      if (256 + t < bsz && start + 256 + t < end) raw_b = load_raw(points, feats, o2p[start + 256 + t]);
-      if (256 + t < bsz && start + bsz + 256 + t < end) next_id_b = o2p[start + bsz + 256 + t];
+      if (PRIMARY + t < bsz && start + PRIMARY + t < end) raw_b = load_raw(points, feats, o2p[start + PRIMARY + t]);
+      if (PRIMARY + t < bsz && start + bsz + PRIMARY + t < end) next_id_b = o2p[start + bsz + PRIMARY + t];
     }
   }
 
@@ -268,7 +281,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       if (t < bsz && begin + bsz + t < end) raw = load_raw(points, feats, next_id);
       if (t < bsz && begin + 2 * bsz + t < end) next_id = o2p[begin + 2 * bsz + t];
       if (t < SLOTS_B) {
-        const int sb = 256 + t;
+        const int sb = PRIMARY + t;
         if (sb < count) {
           write_scan_record(raw_b, rp.alpha_threshold, &s_rec[sb * 3]);
           s_id[sb] = raw_b.id;
@@ -599,6 +612,11 @@ raster_moments_finalize_kernel(const float* __restrict__ points, float* __restri
 
 using namespace ms;
 
+static bool tile32_quarters() {
+  static const bool q = [] { const char* e = getenv("MS_TILE32_BWD"); return e && e[0] == 'q'; }();
+  return q;
+}
+
 static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
@@ -634,7 +652,11 @@ static int launch_scan_backward(const float* points7, const float* features,
   switch (ts) {
     case 8: MS_GO_TILE(8, 1); break;
     case 16: MS_GO_TILE(16, 1); break;
-    default: MS_GO_TILE(16, 2); break;       // tile 32: four quarter workgroups per tile
+    default:
+      // tile 32: ONE 1024-thread workgroup per tile with 896-splat batches (152 KB LDS), or — MS_TILE32_BWD=quarters —
+      // four 16 x 16 quarter workgroups per tile that each stage the whole tile list
+      if (tile32_quarters()) MS_GO_TILE(16, 2); else MS_GO_TILE(32, 1);
+      break;
   }
 #undef MS_GO_TILE
 #undef MS_GO

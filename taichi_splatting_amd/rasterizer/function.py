@@ -33,15 +33,11 @@ DETERMINISTIC_BACKWARD = os.environ.get('MS_DETERMINISTIC', '0') not in ('0', ''
 
 
 def _use_moments_backward(config: RasterConfig, dtype, f: int) -> bool:
-  """Product path (float32 RGB, plain pdf, tile 8 / 16): the splat-per-lane scan kernel of csrc/raster_bwd_scan.hip
-  (config D: 1.43 + 0.14 ms at tile 16, 1.65 + 0.14 ms at tile 8).  At tile 32 the scan kernel runs four 16 x 16
-  quarter workgroups per tile, each staging the whole tile list (3.10 + 0.14 ms, half of it the fourfold staging);
-  the pixel-per-lane kernel of raster_fast.hip takes 3.09 ms there and keeps that tile size — except in the
-  deterministic mode, which only the scan kernel has.  ``MS_RASTER_BWD=patch`` forces the pixel-per-lane kernels
-  (A/B measurements)."""
-  if dtype != torch.float32 or f != 3 or config.antialias or os.environ.get('MS_RASTER_BWD', 'scan') == 'patch':
-    return False
-  return config.tile_size <= 16 or DETERMINISTIC_BACKWARD
+  """Product path (float32 RGB, plain pdf): the splat-per-lane scan kernel of csrc/raster_bwd_scan.hip at every tile
+  size (config D: 1.65 + 0.14 ms at tile 8, 1.43 + 0.14 at tile 16, 1.93 + 0.14 at tile 32 with one 1024-thread
+  workgroup per tile; the pixel-per-lane kernel of raster_fast.hip takes 3.0 ms there).  ``MS_RASTER_BWD=patch``
+  forces the pixel-per-lane kernels (A/B measurements)."""
+  return dtype == torch.float32 and f == 3 and not config.antialias and os.environ.get('MS_RASTER_BWD', 'scan') != 'patch'
 
 
 def _tile_rows(config: RasterConfig, image_size, tile_rows):
