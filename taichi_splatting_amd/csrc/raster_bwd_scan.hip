@@ -46,6 +46,13 @@
 #define MS_SCAN_ABLATE 0
 #endif
 // tile 32 (one 1024-thread workgroup per tile): staged splats per batch / accumulator rows per wave
+// tile 8 (one wave per tile)
+#ifndef MS_T8_BATCH
+#define MS_T8_BATCH 128
+#endif
+#ifndef MS_T8_CAP
+#define MS_T8_CAP 128
+#endif
 #ifndef MS_T32_BATCH
 #define MS_T32_BATCH 896
 #endif
@@ -167,15 +174,15 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // TS == 32 (one 1024-thread workgroup per 32 x 32 tile, 16 waves): an 8x8 patch sees ~1/8 of the tile's splats, so
   // the batch is 896 splats for the per-wave lists to be as long as at tile 16 (~115 patch hits); 43 KB of records +
   // 16 x 6.6 KB per-wave state = 152 of the CU's 160 KB LDS: one workgroup per CU = the same 4 waves per SIMD
-  constexpr int BATCH = TS == 8 ? 128 : TS == 32 ? MS_T32_BATCH : (TS == 16 && !HEUR) ? 268 : 256;
-  constexpr int BATCH_TARGET = TS == 8 ? 112 : TS == 32 ? MS_T32_BATCH - 64 : 256;
+  constexpr int BATCH = TS == 8 ? MS_T8_BATCH : TS == 32 ? MS_T32_BATCH : (TS == 16 && !HEUR) ? 268 : 256;
+  constexpr int BATCH_TARGET = TS == 8 ? MS_T8_BATCH - 16 : TS == 32 ? MS_T32_BATCH - 64 : 256;
   // Patch hits a wave takes on per pass (>= 64: a pass always advances) = rows of its accumulator.  A wave whose
   // patch list overflows runs the rest of the batch as a second pass with nearly empty chunks, so at tile 16 the
   // 40 KB a workgroup may use (four per CU) go to CAP first and to the staging batch second (config D, ms;
   // a batch of ~260 splats puts ~100 on an 8x8 patch):
   //   BATCH / CAP   320 / 112: 1.50    268 / 128: 1.43    256 / 132: 1.51    (3.27 / 3.04 / 3.04 at 4096^2)
   //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
-  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : 128;
+  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : MS_T8_CAP;
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and PRIMARY + t)
   constexpr int PRIMARY = THREADS < BATCH ? THREADS : BATCH;      // slots filled by "thread t stages slot t"
