@@ -112,16 +112,6 @@ __device__ __forceinline__ void wave_scan_add2(float& a, float& b) { MS_SCAN2_AS
 #undef MS_SCAN2_ASM
 #undef MS_SCAN2_STEP
 
-// Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows, the pixel state written by
-// the last lane).  LDS operations of a wave execute in order, but the COMPILER reasons per thread: without a
-// fence it may keep a value this thread loaded earlier instead of re-reading what another lane stored (observed:
-// the <R, G> state was forwarded from registers).  Release + acquire at wavefront scope costs no instruction.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 
 // 48-byte LDS record of a staged splat:

@@ -201,6 +201,15 @@ __device__ __forceinline__ float clamp_alpha(float e, float clamp_max_alpha) {
   return __builtin_amdgcn_fmed3f(e, 0.0f, clamp_max_alpha);
 }
 
+// Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows).  LDS operations of a wave
+// execute in order, but the COMPILER reasons per thread: without a fence it may keep a value this thread loaded earlier
+// instead of re-reading what another lane stored.  Release + acquire at wavefront scope costs no instruction.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int TS> struct TileGeom {
   static constexpr int THREADS = TS * TS;
   static constexpr int BATCH = THREADS < 256 ? THREADS : 256;

@@ -162,6 +162,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   }
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
