@@ -259,7 +259,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
 
   const void* points7 = d.projected_input ? in->points7 : (const void*)(kn + L.points7);
   const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
-  MS_CHECK_ARG(colours != nullptr, "colours are null");
+  MS_CHECK_ARG(d.n == 0 || colours != nullptr, "colours are null");
   return ms_raster_fwd(points7, colours, ranges, o2p, d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha,
                        out_visibility, g.row_begin, g.row_end, d.dtype, stream);
 }

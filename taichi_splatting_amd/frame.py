@@ -165,6 +165,56 @@ def _strip_pixels(rows, tile_size, h):
   return min(rows[0] * tile_size, h), min(rows[1] * tile_size, h)
 
 
+def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr, visibility, device, what):
+  """The two forward calls of the executor plus the eager-mode capacity policy: everything is enqueued with the
+  remembered capacity BEFORE the host looks at the overlap total (pinned word + event), and the emission is re-run with
+  larger buffers in the rare case it did not fit.  Returns (layout, keep_k, capacity, K or None under capture)."""
+  global host_syncs
+  lib = _lib.load()
+  stream = _lib.current_stream(device)
+  capturing = torch.cuda.is_current_stream_capturing()
+  capacity = _k_capacity.get(key, 0)
+  if capturing and capacity == 0:
+    raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
+                       "render one eager frame first or call frame.set_overlap_capacity(...)")
+  k_word, k_event = (None, None) if capturing else _pinned_k(device)
+  _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                        None if capturing else k_word.data_ptr(), None, stream), what)
+  if not capturing:
+    k_event.record(torch.cuda.current_stream(device))
+
+  def map_raster(cap):
+    desc.k_capacity = cap
+    lay = _lib.FrameLayoutC()
+    _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(lay)), what)
+    keep_k = torch.empty((lay.keep_k_bytes,), dtype=torch.uint8, device=device)
+    scratch_k = torch.empty((lay.scratch_k_bytes,), dtype=torch.uint8, device=device)
+    _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                       keep_k.data_ptr(), scratch_k.data_ptr(), image_ptr, alpha_ptr,
+                                       _lib.ptr(visibility), stream), what)
+    return lay, keep_k
+
+  k_total = None
+  if capturing:
+    layout, keep_k = map_raster(capacity)
+  else:
+    if capacity > 0:
+      layout, keep_k = map_raster(capacity)        # everything is enqueued before the host looks at K
+    k_event.synchronize()
+    host_syncs += 1
+    k_total = int(k_word.item())
+    if k_total < 0:
+      raise OverflowError(f"{what}: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
+                          "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
+    if capacity == 0 or k_total > capacity:
+      capacity = _round_capacity(k_total * K_SLACK)
+      if visibility is not None and k_total > 0:
+        visibility.zero_()
+      layout, keep_k = map_raster(capacity)
+    _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+  return layout, keep_k, capacity, k_total
+
+
 class _FrameFunction(torch.autograd.Function):
   """project -> SH -> map -> rasterize as one node (reference: perspective/projection.py:123-188,
   indexed_spherical_harmonics.py:138-160, rasterizer/function.py:42-95 chained by renderer.py:23-108)."""
@@ -172,7 +222,6 @@ class _FrameFunction(torch.autograd.Function):
   @staticmethod
   def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
               opts: FrameOptions, state: FrameState):
-    global host_syncs
     lib = _lib.load()
     _lib.require_gpu(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection)
     tensors = [t.detach().contiguous() for t in
@@ -201,13 +250,7 @@ class _FrameFunction(torch.autograd.Function):
 
     rows = (0, tiles_high) if opts.tile_rows is None else (max(0, int(opts.tile_rows[0])), min(tiles_high, int(opts.tile_rows[1])))
     key = _shape_key(device, n, (w, h), config, opts.tile_rows, opts.use_depth16)
-    capturing = torch.cuda.is_current_stream_capturing()
-    capacity = _k_capacity.get(key, 0)
-    if capturing and capacity == 0:
-      raise RuntimeError("render_gaussians under HIP-graph capture: the overlap-list capacity of this scene shape is "
-                         "unknown; render one eager frame first or call frame.set_overlap_capacity(...)")
-
-    desc = _lib.FrameDescC(n=n, k_capacity=capacity, image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
+    desc = _lib.FrameDescC(n=n, k_capacity=_k_capacity.get(key, 0), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
                            sh_degree=degree, depth16=int(opts.use_depth16), tile_row_begin=rows[0], tile_row_end=rows[1],
                            projected_input=0, reserved=0, near_plane=float(opts.depth_range[0]),
                            far_plane=float(opts.depth_range[1]), blur_cov=float(config.blur_cov),
@@ -221,12 +264,6 @@ class _FrameFunction(torch.autograd.Function):
                                alpha_logit=alog.data_ptr(), feature=feat.data_ptr(), T_camera_world=Tcw.data_ptr(),
                                projection=proj.data_ptr(), points7=None, depth=None, colours=None)
 
-    k_word, k_event = (None, None) if capturing else _pinned_k(device)
-    _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
-                                          None if capturing else k_word.data_ptr(), None, stream), "render_gaussians")
-    if not capturing:
-      k_event.record(torch.cuda.current_stream(device))
-
     # images: with crop_to_rows only the strip's pixel rows exist; the kernels address absolute rows, so they get the
     # address row 0 WOULD have (they touch rows [y0, y1) only)
     y0, y1 = _strip_pixels(rows, ts, h) if opts.crop_to_rows else (0, h)
@@ -237,38 +274,9 @@ class _FrameFunction(torch.autograd.Function):
     visibility = torch.zeros((n,), dtype=dtype, device=device) if config.compute_visibility else torch.empty((0,), dtype=dtype, device=device)
     heuristic = torch.zeros((n, 2), dtype=dtype, device=device) if config.compute_point_heuristic else torch.empty((0, 2), dtype=dtype, device=device)
     es = image.element_size()
-
-    def map_raster(cap):
-      desc.k_capacity = cap
-      lay = _lib.FrameLayoutC()
-      _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(lay)), "render_gaussians")
-      keep_k = torch.empty((lay.keep_k_bytes,), dtype=torch.uint8, device=device)
-      scratch_k = torch.empty((lay.scratch_k_bytes,), dtype=torch.uint8, device=device)
-      _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
-                                         keep_k.data_ptr(), scratch_k.data_ptr(),
-                                         image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es,
-                                         visibility.data_ptr() if config.compute_visibility else None, stream),
-                 "render_gaussians")
-      return lay, keep_k
-
-    k_total = None
-    if capturing:
-      layout, keep_k = map_raster(capacity)
-    else:
-      if capacity > 0:
-        layout, keep_k = map_raster(capacity)        # everything is enqueued before the host looks at K
-      k_event.synchronize()
-      host_syncs += 1
-      k_total = int(k_word.item())
-      if k_total < 0:
-        raise OverflowError("render_gaussians: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
-                            "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-      if capacity == 0 or k_total > capacity:
-        capacity = _round_capacity(k_total * K_SLACK)
-        if config.compute_visibility and k_total > 0:
-          visibility.zero_()
-        layout, keep_k = map_raster(capacity)
-      _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+    layout, keep_k, capacity, k_total = _enqueue_forward(
+      desc, inputs, keep_n, scratch_n, key, image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es,
+      visibility if config.compute_visibility else None, device, "render_gaussians")
 
     state.desc, state.layout, state.inputs = desc, layout, inputs
     state.keep_n, state.keep_k, state.k, state.capacity, state.y0 = keep_n, keep_k, k_total, capacity, y0
@@ -418,6 +426,102 @@ class _FrameFunction(torch.autograd.Function):
       if need[6]:
         grad_proj = grad_camera[12:16].clone()
     return (*grads, grad_feature, grad_T, grad_proj, None, None)
+
+
+class _RasterizeFrameFunction(torch.autograd.Function):
+  """``rasterize(gaussians2d, depth, features, ...)`` (reference rasterizer/function.py:133-165: map_to_tiles +
+  rasterize_with_tiles) on the executor's ``projected_input`` mode: one node, no host read of the overlap total
+  before the frame is enqueued.  Differentiable w.r.t. gaussians2d and features, like the reference."""
+
+  @staticmethod
+  def forward(ctx, gaussians2d, depth, features, image_size, config, use_depth16, state):
+    lib = _lib.load()
+    _lib.require_gpu(gaussians2d, depth, features)
+    assert gaussians2d.ndim == 2 and gaussians2d.shape[1] == 7, f"gaussians2d must be (N, 7), got {gaussians2d.shape}"
+    assert features.ndim == 2 and features.shape[0] == gaussians2d.shape[0], \
+      f"features must be (N, F), got {features.shape} for {gaussians2d.shape[0]} gaussians"
+    assert features.dtype == gaussians2d.dtype, f"dtype mismatch {features.dtype} != {gaussians2d.dtype}"
+    if config.compute_visibility and not config.use_alpha_blending:
+      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
+                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
+    p = gaussians2d.detach().contiguous()
+    feats = features.detach().contiguous()
+    dtype, device = p.dtype, p.device
+    d = depth.detach().reshape(-1).to(dtype).contiguous()      # sort keys are float32 bits of the depth either way
+    n, f = feats.shape
+    w, h = int(image_size[0]), int(image_size[1])
+    key = ('2d',) + _shape_key(device, n, (w, h), config, None, use_depth16)
+    desc = _lib.FrameDescC(n=n, k_capacity=_k_capacity.get(key, 0), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
+                           sh_degree=-1, depth16=int(use_depth16), tile_row_begin=0, tile_row_end=1 << 30,
+                           projected_input=1, reserved=0, near_plane=0.0, far_plane=0.0, blur_cov=0.0, clamp_margin=0.0,
+                           raster=_lib.raster_config_c(config))
+    layout = _lib.FrameLayoutC()
+    _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(layout)), "rasterize")
+    keep_n = torch.empty((layout.keep_n_bytes,), dtype=torch.uint8, device=device)
+    scratch_n = torch.empty((layout.scratch_n_bytes,), dtype=torch.uint8, device=device)
+    inputs = _lib.FrameInputsC(points7=p.data_ptr(), depth=d.data_ptr(), colours=feats.data_ptr())
+    image = torch.empty((h, w, f), dtype=dtype, device=device)
+    alpha = torch.empty((h, w), dtype=dtype, device=device)
+    visibility = torch.zeros((n,), dtype=dtype, device=device) if config.compute_visibility else torch.empty((0,), dtype=dtype, device=device)
+    heuristic = torch.zeros((n, 2), dtype=dtype, device=device) if config.compute_point_heuristic else torch.empty((0, 2), dtype=dtype, device=device)
+    layout, keep_k, capacity, k_total = _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image.data_ptr(), alpha.data_ptr(),
+                                                         visibility if config.compute_visibility else None, device, "rasterize")
+    state.desc, state.layout, state.inputs = desc, layout, inputs
+    state.keep_n, state.keep_k, state.k, state.capacity = keep_n, keep_k, k_total, capacity
+    state.tensors = (p, d, feats)
+    ctx.set_materialize_grads(False)
+    ctx.state, ctx.config, ctx.size, ctx.heuristic = state, config, (w, h), heuristic
+    ctx.save_for_backward(p, feats, image)
+    ctx.mark_non_differentiable(alpha, heuristic, visibility)
+    return image, alpha, heuristic, visibility
+
+  @staticmethod
+  def backward(ctx, g_image, g_alpha, g_heur, g_vis):
+    from .rasterizer import function as raster_function
+    lib = _lib.load()
+    p, feats, image = ctx.saved_tensors
+    state, config = ctx.state, ctx.config
+    need_points, _, need_features = ctx.needs_input_grad[:3]
+    heuristic = ctx.heuristic if config.compute_point_heuristic else None
+    if g_image is None or not (need_points or need_features or heuristic is not None):
+      return (None,) * 7
+    n, f = feats.shape
+    device, dtype = p.device, p.dtype
+    if n == 0:
+      return torch.zeros_like(p), None, torch.zeros_like(feats), None, None, None, None
+    det = bool(raster_function.DETERMINISTIC_BACKWARD)
+    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(state.desc), int(det)))
+    make = torch.empty if moments_path else torch.zeros        # the finalize pass stores, the generic kernels accumulate
+    gp = make((n, 7), dtype=dtype, device=device)
+    gf = make((n, f), dtype=dtype, device=device)
+    g_image = g_image.contiguous()
+    gr = _lib.FrameGradsC()
+    gr.image, gr.grad_image = image.data_ptr(), g_image.data_ptr()
+    gr.grad_points7, gr.grad_colours = gp.data_ptr(), gf.data_ptr()
+    fixed_exp = None
+    if moments_path:
+      gr.moments = _moments_buffer(device, n, det).data_ptr()
+      gr.deterministic = int(det)
+      if det:
+        fixed_exp = _lib.fixed_point_exponents(g_image)
+        gr.fixed_exp = fixed_exp.data_ptr()
+    if heuristic is not None:
+      gr.point_heuristic = heuristic.data_ptr()
+    try:
+      _lib.check(lib.ms_frame_backward(ctypes.byref(state.desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
+                                       state.keep_k.data_ptr(), ctypes.byref(gr), _lib.current_stream(device)),
+                 "rasterize backward")
+    except Exception:
+      _moments.clear()
+      raise
+    return (gp if need_points else None), None, (gf if need_features else None), None, None, None, None
+
+
+def rasterize_frame(gaussians2d, depth, features, image_size, config: RasterConfig, use_depth16: bool = False):
+  """``rasterize`` on the frame executor; returns (image, image_weight, point_heuristic, visibility)."""
+  state = FrameState()
+  return _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
+                                       bool(use_depth16), state)
 
 
 class LazyPoints:

@@ -257,6 +257,12 @@ def rasterize(gaussians2d: torch.Tensor, depth: torch.Tensor, features: torch.Te
   assert gaussians2d.shape[0] == depth.shape[0] == features.shape[0], \
     f"Size mismatch: got {gaussians2d.shape}, {depth.shape}, {features.shape}"
 
+  from .. import frame
+  if (frame.USE_FRAME and features.ndim == 2 and 1 <= features.shape[1] <= MAX_KERNEL_FEATURES and gaussians2d.is_cuda
+      and depth.dtype in (torch.float32, torch.float64)):
+    # one node on the frame executor (projected input): no host read of the overlap total before the frame is enqueued
+    return RasterOut(*frame.rasterize_frame(gaussians2d, depth, features, image_size, config, use_depth16))
+
   overlap_to_point, tile_overlap_ranges = map_to_tiles(
     gaussians2d, depth, image_size=image_size, config=config, use_depth16=use_depth16)
 

@@ -253,3 +253,35 @@ def test_frame_under_hip_graph_capture():
     frame.USE_FRAME = True
   assert torch.equal(r.image, want)
   assert not frame.frame_status(r)['overflow']
+
+
+@pytest.mark.parametrize('dtype,channels,tile', [(torch.float32, 3, 16), (torch.float32, 1, 8), (torch.float64, 3, 16), (torch.float32, 3, 32)])
+def test_rasterize_2d_on_the_executor_equals_modular(dtype, channels, tile):
+  # rasterize() (reference rasterizer/function.py:133-165) = map_to_tiles + rasterize_with_tiles; on the executor's
+  # projected-input mode it is one node without a host read of the overlap total
+  from taichi_splatting_amd import rasterize
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  torch.manual_seed(3)
+  size = (200, 144)
+  g = random_2d_gaussians(6000, size, num_channels=channels, scale_factor=2.0, alpha_range=(0.2, 0.9)).to(DEV)
+  p, f, d = project_gaussians2d(g).to(dtype), g.feature.to(dtype).contiguous(), g.depths
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2), compute_visibility=True,
+                     compute_point_heuristic=True)
+  G = torch.randn(size[1], size[0], channels, device=DEV, dtype=dtype)
+  res = []
+  for use_frame in (True, False):
+    frame.USE_FRAME = use_frame
+    try:
+      pg, fg = p.clone().requires_grad_(True), f.clone().requires_grad_(True)
+      out = rasterize(pg, d, fg, size, cfg)
+      (out.image * G).sum().backward()
+      res.append((out, pg.grad, fg.grad))
+    finally:
+      frame.USE_FRAME = True
+  (a, gpa, gfa), (b, gpb, gfb) = res
+  assert torch.equal(a.image, b.image) and torch.equal(a.image_weight, b.image_weight)
+  tol = 1e-9 if dtype == torch.float64 else 5e-5
+  assert torch.allclose(a.visibility, b.visibility, rtol=1e-4, atol=1e-5)
+  for x, y in ((gpa, gpb), (gfa, gfb), (a.point_heuristic, b.point_heuristic)):
+    assert float((x - y).abs().max()) <= tol * float(y.abs().max()), float((x - y).abs().max()) / float(y.abs().max())
