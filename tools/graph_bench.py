@@ -1,4 +1,4 @@
-"""eager vs HIP-graph replay of the fwd+bwd step: python tools/dbg/graph_bench.py n size [tile]"""
+"""eager vs HIP-graph replay of the fwd+bwd step: python tools/graph_bench.py n size [tile]"""
 import sys, time; sys.path.insert(0, '.')
 import torch
 from taichi_splatting_amd import RasterConfig, frame, render_gaussians
