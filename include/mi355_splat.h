@@ -248,11 +248,13 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  *
  * ms_frame_project:        the per-gaussian stage alone (camera position, projection, SH colours) into keep_n — what a
  *     rank of the gaussian-sharded multi-GPU step runs on its shard before the exchange.
- * ms_frame_project_count:  ms_frame_project, then depth pre-sort, overlap count, scan, K.
+ * ms_frame_project_count:  camera position, projection, depth pre-sort, overlap count, scan, K (the SH colours are
+ *     evaluated by ms_frame_map_raster: nothing before the raster forward needs them, and a host that looks at K
+ *     then finds the long SH pass queued behind the K kernel, not in front of it).
  *     projected_input != 0 (2-D path, splats received for a multi-GPU strip): in->points7 / depth / colours are
  *     used as they are and nothing is culled by depth.  k_host (pinned host int32, may be NULL) receives K;
  *     k_event (hipEvent_t, may be NULL) is recorded right after the kernel that writes it.
- * ms_frame_map_raster:     emission, stable sort on the tile id, tile ranges, raster forward.
+ * ms_frame_map_raster:     SH colours, emission, stable sort on the tile id, tile ranges, raster forward.
  * ms_frame_backward:       raster backward + ONE pass over the gaussians (moment rows -> 2D gradients -> projection
  *     backward -> SH backward; csrc/gaussian_bwd.hip).  ms_frame_uses_moments(desc) != 0: the product raster
  *     backward runs and g->moments (n, MS_MOMENT_ROW) must be zero on entry and is zero again on return;

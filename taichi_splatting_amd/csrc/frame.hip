@@ -143,27 +143,36 @@ extern "C" int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministi
     if (rc__ != 0) return rc__; \
   } while (0)
 
-extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream) {
-  MS_TRY(check_desc(desc, "ms_frame_project"));
-  MS_CHECK_ARG(in && keep_n, "null pointer");
+// per-gaussian forward stage into keep_n: camera position + projection (+ SH colours)
+static int frame_project_impl(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, bool projection,
+                              bool colours, void* stream, const char* who) {
   const ms_frame_desc& d = *desc;
-  MS_CHECK_ARG(!d.projected_input, "projected input has no per-gaussian stage");
+  if (d.projected_input) { set_error("%s: projected input has no per-gaussian stage", who); return MS_ERR_BAD_ARG; }
   if (d.n == 0) return 0;
   ms_frame_layout L;
   frame_layout(desc, &L);
   char* kn = (char*)keep_n;
-  MS_CHECK_ARG(in->position && in->log_scaling && in->rotation && in->alpha_logit && in->T_camera_world && in->projection,
-               "null gaussian / camera input");
-  MS_CHECK_ARG(in->feature != nullptr, "feature is null");
-  if (d.sh_degree >= 0)
-    MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
-  MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
-                        d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
-                        d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
-  if (d.sh_degree >= 0)
+  if (!(in->position && in->log_scaling && in->rotation && in->alpha_logit && in->T_camera_world && in->projection)) {
+    set_error("%s: null gaussian / camera input", who); return MS_ERR_BAD_ARG;
+  }
+  if (!in->feature) { set_error("%s: feature is null", who); return MS_ERR_BAD_ARG; }
+  if (projection) {
+    if (d.sh_degree >= 0)
+      MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
+    MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
+                          d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
+                          d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
+  }
+  if (colours && d.sh_degree >= 0)
     MS_TRY(sh_fwd_inplace_launch(in->feature, in->position, kn + L.depth, kn + L.camera_position, d.n, d.f,
                                  d.sh_degree, kn + L.colours, d.dtype, (hipStream_t)stream));
   return 0;
+}
+
+extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_project"));
+  MS_CHECK_ARG(in && keep_n, "null pointer");
+  return frame_project_impl(desc, in, keep_n, true, true, stream, "ms_frame_project");
 }
 
 extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
@@ -189,7 +198,10 @@ extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_
   const void* points7;
   const void* depth;
   if (!d.projected_input) {
-    MS_TRY(ms_frame_project(desc, in, keep_n, stream));
+    // projection only: the SH colours are not needed before the raster forward and are evaluated by
+    // ms_frame_map_raster — AFTER the kernels that produce K, so that a host that looks at K (eager mode) finds the
+    // long SH pass still queued behind it instead of in front of it
+    MS_TRY(frame_project_impl(desc, in, keep_n, true, false, stream, "ms_frame_project_count"));
     points7 = kn + L.points7;
     depth = kn + L.depth;
   } else {
@@ -242,6 +254,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   int32_t* o2p = (int32_t*)(kk + L.overlap_to_point);
 
   frame_k_limit_kernel<<<1, 1, 0, s>>>(counters, (int32_t)d.k_capacity);
+  if (!d.projected_input) MS_TRY(frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_map_raster"));
   if (d.n > 0 && d.k_capacity > 0) {
     MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
     uint32_t* keys = (uint32_t*)(sk + L.keys);

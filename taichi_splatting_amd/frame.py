@@ -81,12 +81,29 @@ def _round_capacity(k: int) -> int:
   return min((k + K_GRANULE - 1) // K_GRANULE * K_GRANULE, (1 << 31) - 1)
 
 
+K_PENDING = -(1 << 31)      # sentinel the host writes into the pinned word before a frame; K itself is >= 0
+
+
 def _pinned_k(device):
+  """(pinned int32 word the frame's K kernel writes, its numpy view for polling, an event as the fallback wait)"""
   entry = _k_host.get(device.index)
   if entry is None:
     word = torch.zeros((1,), dtype=torch.int32).pin_memory()
-    entry = _k_host[device.index] = (word, torch.cuda.Event())
+    entry = _k_host[device.index] = (word, word.numpy(), torch.cuda.Event())
   return entry
+
+
+def _wait_for_k(k_np, k_event) -> int:
+  """The host's one wait per eager frame.  Polling the pinned word the K kernel writes returns within microseconds of
+  the write; ``Event.synchronize`` (an interrupt-driven sleep) cost 0.3-0.5 ms of wake-up latency per frame, which
+  at 1 M gaussians left the GPU idle for a third of the frame."""
+  import time
+  deadline = time.perf_counter() + 2.0
+  while k_np[0] == K_PENDING:
+    if time.perf_counter() > deadline:      # never seen; a lost write must not hang the caller
+      k_event.synchronize()
+      break
+  return int(k_np[0])
 
 
 def identity_indexes(n: int, device) -> torch.Tensor:
@@ -127,6 +144,11 @@ class FrameState:
     self.capacity = 0
     self.children = []            # (weakref to a tensor handed out, index list or None, 'points7' | 'colours')
     self.y0 = 0
+    self.pending = None           # eager mode: the wait for K + capacity check, run once by the frame's caller
+
+  def settle(self):
+    if self.pending is not None:
+      self.pending()
 
   def counters(self) -> torch.Tensor:
     return self.keep_n[self.layout.counters:self.layout.counters + 32].view(torch.int32)
@@ -165,10 +187,13 @@ def _strip_pixels(rows, tile_size, h):
   return min(rows[0] * tile_size, h), min(rows[1] * tile_size, h)
 
 
-def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr, visibility, device, what):
+def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr, visibility, device, what, state,
+                     settle_now=False):
   """The two forward calls of the executor plus the eager-mode capacity policy: everything is enqueued with the
-  remembered capacity BEFORE the host looks at the overlap total (pinned word + event), and the emission is re-run with
-  larger buffers in the rare case it did not fit.  Returns (layout, keep_k, capacity, K or None under capture)."""
+  remembered capacity BEFORE the host looks at the overlap total (a pinned word the K kernel writes), and the emission
+  is re-run with larger buffers in the rare case it did not fit.  Fills ``state`` (layout, keep_k, capacity, k) and
+  leaves ``state.pending`` = the settle step (the wait + check) for the caller to run as the LAST thing it does for
+  this frame — the later the host looks, the more of its own per-frame work is hidden behind queued GPU work."""
   global host_syncs
   lib = _lib.load()
   stream = _lib.current_stream(device)
@@ -177,7 +202,9 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")
-  k_word, k_event = (None, None) if capturing else _pinned_k(device)
+  k_word, k_np, k_event = (None, None, None) if capturing else _pinned_k(device)
+  if not capturing:
+    k_np[0] = K_PENDING
   _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
                                         None if capturing else k_word.data_ptr(), None, stream), what)
   if not capturing:
@@ -192,27 +219,35 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
                                        keep_k.data_ptr(), scratch_k.data_ptr(), image_ptr, alpha_ptr,
                                        _lib.ptr(visibility), stream), what)
-    return lay, keep_k
+    state.layout, state.keep_k, state.capacity = lay, keep_k, cap
 
-  k_total = None
+  state.k, state.pending = None, None
   if capturing:
-    layout, keep_k = map_raster(capacity)
-  else:
-    if capacity > 0:
-      layout, keep_k = map_raster(capacity)        # everything is enqueued before the host looks at K
-    k_event.synchronize()
+    map_raster(capacity)
+    return
+
+  def settle():
+    global host_syncs
+    state.pending = None
+    k_total = _wait_for_k(k_np, k_event)
     host_syncs += 1
-    k_total = int(k_word.item())
     if k_total < 0:
       raise OverflowError(f"{what}: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
                           "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-    if capacity == 0 or k_total > capacity:
-      capacity = _round_capacity(k_total * K_SLACK)
+    if state.capacity == 0 or k_total > state.capacity:
       if visibility is not None and k_total > 0:
         visibility.zero_()
-      layout, keep_k = map_raster(capacity)
+      map_raster(_round_capacity(k_total * K_SLACK))
+    state.k = k_total
     _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
-  return layout, keep_k, capacity, k_total
+
+  state.capacity = 0
+  if capacity > 0:
+    map_raster(capacity)          # everything is enqueued before the host looks at K
+  if capacity == 0 or settle_now:
+    settle()
+  else:
+    state.pending = settle
 
 
 class _FrameFunction(torch.autograd.Function):
@@ -274,13 +309,12 @@ class _FrameFunction(torch.autograd.Function):
     visibility = torch.zeros((n,), dtype=dtype, device=device) if config.compute_visibility else torch.empty((0,), dtype=dtype, device=device)
     heuristic = torch.zeros((n, 2), dtype=dtype, device=device) if config.compute_point_heuristic else torch.empty((0, 2), dtype=dtype, device=device)
     es = image.element_size()
-    layout, keep_k, capacity, k_total = _enqueue_forward(
-      desc, inputs, keep_n, scratch_n, key, image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es,
-      visibility if config.compute_visibility else None, device, "render_gaussians")
-
-    state.desc, state.layout, state.inputs = desc, layout, inputs
-    state.keep_n, state.keep_k, state.k, state.capacity, state.y0 = keep_n, keep_k, k_total, capacity, y0
+    state.desc, state.inputs, state.keep_n, state.y0 = desc, inputs, keep_n, y0
     state.tensors = tensors                                  # the pointers in `inputs` stay valid
+    _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image.data_ptr() - y0 * w * f * es,
+                     alpha.data_ptr() - y0 * w * es, visibility if config.compute_visibility else None, device,
+                     "render_gaussians", state, settle_now=opts.render_median_depth)
+    layout = state.layout
 
     points7 = _view(keep_n, layout.points7, dtype, (n, 7))
     depth = _view(keep_n, layout.depth, dtype, (n,))
@@ -317,6 +351,7 @@ class _FrameFunction(torch.autograd.Function):
     lib = _lib.load()
     pos, lsc, rot, alog, feat, Tcw, proj, image = ctx.saved_tensors
     state, opts = ctx.state, ctx.opts
+    state.settle()              # (already done by render_frame; a caller of the bare Function gets it here)
     desc, config = state.desc, opts.config
     n, f = pos.shape[0], ctx.f
     device, dtype = pos.device, pos.dtype
@@ -464,11 +499,10 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     alpha = torch.empty((h, w), dtype=dtype, device=device)
     visibility = torch.zeros((n,), dtype=dtype, device=device) if config.compute_visibility else torch.empty((0,), dtype=dtype, device=device)
     heuristic = torch.zeros((n, 2), dtype=dtype, device=device) if config.compute_point_heuristic else torch.empty((0, 2), dtype=dtype, device=device)
-    layout, keep_k, capacity, k_total = _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image.data_ptr(), alpha.data_ptr(),
-                                                         visibility if config.compute_visibility else None, device, "rasterize")
-    state.desc, state.layout, state.inputs = desc, layout, inputs
-    state.keep_n, state.keep_k, state.k, state.capacity = keep_n, keep_k, k_total, capacity
+    state.desc, state.inputs, state.keep_n = desc, inputs, keep_n
     state.tensors = (p, d, feats)
+    _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image.data_ptr(), alpha.data_ptr(),
+                     visibility if config.compute_visibility else None, device, "rasterize", state)
     ctx.set_materialize_grads(False)
     ctx.state, ctx.config, ctx.size, ctx.heuristic = state, config, (w, h), heuristic
     ctx.save_for_backward(p, feats, image)
@@ -481,6 +515,7 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     lib = _lib.load()
     p, feats, image = ctx.saved_tensors
     state, config = ctx.state, ctx.config
+    state.settle()
     need_points, _, need_features = ctx.needs_input_grad[:3]
     heuristic = ctx.heuristic if config.compute_point_heuristic else None
     if g_image is None or not (need_points or need_features or heuristic is not None):
@@ -520,8 +555,10 @@ class _RasterizeFrameFunction(torch.autograd.Function):
 def rasterize_frame(gaussians2d, depth, features, image_size, config: RasterConfig, use_depth16: bool = False):
   """``rasterize`` on the frame executor; returns (image, image_weight, point_heuristic, visibility)."""
   state = FrameState()
-  return _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
-                                       bool(use_depth16), state)
+  out = _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
+                                      bool(use_depth16), state)
+  state.settle()
+  return out
 
 
 class LazyPoints:
@@ -581,6 +618,7 @@ def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, u
   rendering = Rendering(image=image, image_weight=alpha, depth_image=None, median_depth_image=median, points=points,
                         camera=camera_params, config=config)
   object.__setattr__(rendering, 'frame', state)
+  state.settle()             # the host's one look at the overlap total: last, behind everything it had to do anyway
   return rendering
 
 

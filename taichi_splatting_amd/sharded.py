@@ -180,7 +180,7 @@ class StripStep(_RankStep):
   gradients.  ``step(gaussians, camera, loss_fn)``: ``loss_fn(strip_image, (y0, y1))`` gets ONLY the strip's pixel
   rows; afterwards ``.grad`` of the gaussians' leaf tensors holds the full gradient (identical on every rank)."""
 
-  def probe(self, gaussians: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.3):
+  def probe(self, gaussians: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.15):
     """one synchronising dry run: fixes the overlap-list capacity of this rank's strip"""
     from .mapper.tile_mapper import map_to_tiles_strip
     from .perspective.projection import project_to_image
@@ -276,7 +276,7 @@ class ShardedStep(_RankStep):
     self.bucket_capacity = 0
     self.exchange = exchange or (lambda recv, send: _exchange_all_to_all(recv, send, self.group))
 
-  def probe(self, shard: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.3, exchange=None):
+  def probe(self, shard: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.15, exchange=None):
     """one synchronising dry run (a collective: every rank calls it): the largest per-destination bucket over all
     ranks fixes the bucket capacity, this rank's strip fixes its overlap-list capacity.  ``exchange``: the
     variable-size all-to-all of ``distributed.exchange_to_strips`` (default: RCCL)"""

@@ -161,7 +161,7 @@ def main_static(args):
 
   def timed(fn, steps=None):
     steps = steps or max(args.steps, 20)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 10)):
       fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
