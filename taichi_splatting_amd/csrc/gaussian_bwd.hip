@@ -17,7 +17,21 @@
 #include "raster_common.h"
 #include "frame_internal.h"
 
+#ifndef MS_GB_NT
+#define MS_GB_NT 1
+#endif
+
 namespace ms {
+
+// gradient rows are written once and read by somebody else much later (the optimiser): streaming stores
+template <typename V>
+__device__ __forceinline__ void stream_store(V* p, V v) {
+#if MS_GB_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 constexpr int GB_MAX_F = 4;      // SH colour channels (sh.hip: SH_MAX_F)
 
@@ -158,17 +172,17 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
     if (valid) {
       if (a.grad_position) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) a.grad_position[i * 3 + k] = dp[k];
+        for (int k = 0; k < 3; ++k) stream_store(&a.grad_position[i * 3 + k], dp[k]);
       }
       if (a.grad_log_scaling) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) a.grad_log_scaling[i * 3 + k] = dls[k];
+        for (int k = 0; k < 3; ++k) stream_store(&a.grad_log_scaling[i * 3 + k], dls[k]);
       }
       if (a.grad_rotation) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a.grad_rotation[i * 4 + k] = dq[k];
+        for (int k = 0; k < 4; ++k) stream_store(&a.grad_rotation[i * 4 + k], dq[k]);
       }
-      if (a.grad_alpha_logit) a.grad_alpha_logit[i] = dal;
+      if (a.grad_alpha_logit) stream_store(&a.grad_alpha_logit[i], dal);
       if (a.store_points7) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) a.store_points7[i * 7 + k] = gp[k];
@@ -199,8 +213,9 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
             const int c = (4 * k) / D, d0 = 4 * k - c * D;
             const T g = s_g[wave][j * GB_MAX_F + c];
             const T* y = &s_Y[wave][j * YS + d0];
-            const float4 val = make_float4((float)(g * y[0]), (float)(g * y[1]), (float)(g * y[2]), (float)(g * y[3]));
-            reinterpret_cast<float4*>(dst0)[qi] = val;
+            typedef float vec4 __attribute__((ext_vector_type(4)));
+            const vec4 val = {(float)(g * y[0]), (float)(g * y[1]), (float)(g * y[2]), (float)(g * y[3])};
+            stream_store(reinterpret_cast<vec4*>(dst0) + qi, val);
           }
         } else {
           for (int e = lane; e < count * row; e += 64) {
