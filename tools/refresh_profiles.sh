@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 python bench.py > "$out/bench.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-stages --no-graph --no-sweep > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-stages --no-graph --no-sweep --spin-up 0 > "$out/trace.log" 2>&1
 db=$(find "$out/trace" -name '*_results.db' | head -1)
 if [ -n "$db" ]; then python tools/rocpd_stats.py "$db" --steps 18 > "$out/kernel_trace.txt"; rm -f "$db"; fi
 find "$out/trace" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
