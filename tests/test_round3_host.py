@@ -73,8 +73,8 @@ def test_frame_layout_query_and_dispatch_without_a_gpu():
   offsets = [lay.points7, lay.depth, lay.colours, lay.camera_position, lay.counters, lay.tile_ranges]
   assert offsets == sorted(offsets) and all(o % 256 == 0 for o in offsets)
   assert lib.ms_frame_uses_moments(ctypes.byref(d), 0) == 1
-  d.raster.tile_size = 32
-  assert lib.ms_frame_uses_moments(ctypes.byref(d), 0) == 0 and lib.ms_frame_uses_moments(ctypes.byref(d), 1) == 1
+  d.raster.tile_size = 32                # the scan backward serves every tile size since the 1024-thread tile-32 variant
+  assert lib.ms_frame_uses_moments(ctypes.byref(d), 0) == 1 and lib.ms_frame_uses_moments(ctypes.byref(d), 1) == 1
   d.raster.tile_size = 16; d.raster.antialias = 1
   assert lib.ms_frame_uses_moments(ctypes.byref(d), 0) == 0
   d.f = 7                        # no instantiation: argument error, not a crash
