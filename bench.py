@@ -11,10 +11,16 @@ already resident in HBM.  Default workload = BASELINE.json configs[3] ("config D
 N > 1: one rank per GPU over RCCL, either launched by ``torch.distributed.run`` (RANK / WORLD_SIZE in the
 environment) or, when ``--gpus N`` is given without that environment, by this script re-executing itself under
 ``torch.distributed.run`` on 127.0.0.1.  The SAME frame is rendered by the N ranks ("scaling": "strong") in both
-decompositions of taichi_splatting_amd/distributed.py, each timed for K steps: ``strips`` (north_star: gaussians
-replicated, tile-row strips, all-reduce of the 2D-boundary gradients) and ``sharded`` (gaussians sharded by
-index, all-to-all of projected splats and of their gradients).  ``value`` is the faster of the two, named in
-``config.parallelism``; both are in ``modes`` with per-rank times and the bytes each rank exchanges per step.
+decompositions, each timed for K steps with the sync-free rank steps of taichi_splatting_amd/sharded.py
+(``--legacy-steps``: the round-2 steps of distributed.py): ``strips`` (north_star: gaussians replicated, tile-row
+strips, reduce-scatter + all-gather of the 2D-boundary gradients) and ``sharded`` (gaussians sharded by index,
+fixed-capacity all-to-all of projected splats and of their gradients).  ``value`` is the faster of the two, named in
+``config.parallelism``; both are in ``modes`` with per-rank times, per-rank per-stage GPU times (HIP events) and the
+bytes each rank exchanges per step; ``job`` holds the world size, every rank's device and the RCCL version as the
+process group reports them.
+
+N = 1: ``render_gaussians(...).image.sum().backward()`` per step (the frame executor), plus the same step replayed from a
+HIP graph (``graph_ms_per_step``, timed in a child process) and the tile 8 / 16 / 32 sweep BASELINE.json names.
 
 Prints ONE JSON line on rank 0 (metric, roofline of the dominant kernel, CPU-oracle baseline).
 """
