@@ -213,7 +213,7 @@ def test_empty_and_all_culled_scenes():
   fd = far.clone().requires_grad_(True)
   r = render_gaussians(fd, cam, cfg, use_sh=True)
   r.image.sum().backward()
-  assert float(r.image.abs().max()) == 0.0 and len(r.points) == 0
+  assert float(r.image.detach().abs().max()) == 0.0 and len(r.points) == 0
   assert float(fd.position.grad.abs().max()) == 0.0 and float(fd.feature.grad.abs().max()) == 0.0
 
 

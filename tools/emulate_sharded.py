@@ -202,7 +202,7 @@ def main_static(args):
       _, _, _, _, plan = exchange_to_strips(g2d, feats, depths, size, cfg, bounds, global_index=idx,
                                             index_offset=steps_[r].index_offset, exchange=loop, return_plan=True)
       biggest = max(biggest, max(plan.send_counts))
-  cap = (int(biggest * 1.3) + 255) // 256 * 256
+  cap = (int(biggest * 1.15) + 255) // 256 * 256
   for st in steps_:
     st.bucket_capacity = cap
     st.k_capacity = 1 << 26             # generous for the recording pass; fixed per rank below
@@ -228,7 +228,7 @@ def main_static(args):
     st.exchange = ex
     with torch.no_grad():
       st.step(shard, cam, loss_fn, use_sh=True, backward=False)
-    st.k_capacity = frame._round_capacity(int(st.check()['overlaps']) * 1.3)
+    st.k_capacity = frame._round_capacity(int(st.check()['overlaps']) * 1.15)
     leaves = (shard.position, shard.log_scaling, shard.rotation, shard.alpha_logit, shard.feature)
 
     def step():
