@@ -106,6 +106,15 @@ def _wait_for_k(k_np, k_event) -> int:
   return int(k_np[0])
 
 
+def release_caches():
+  """Drop what the executor keeps between frames: the persistent moments accumulators (64 B per gaussian), the shared
+  identity index lists, the remembered overlap capacities and the pinned K words."""
+  _moments.clear()
+  _identity.clear()
+  _k_capacity.clear()
+  _k_host.clear()
+
+
 def identity_indexes(n: int, device) -> torch.Tensor:
   """arange(n) int64, shared: callers treat index lists as read-only.  Built outside inference mode so that a first
   use under ``torch.inference_mode()`` (evaluation render) does not poison later training frames."""
