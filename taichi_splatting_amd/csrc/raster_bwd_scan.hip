@@ -27,8 +27,8 @@
 //     raster_moments_finalize_kernel (or by the fused projection/SH backward) instead of once per pixel;
 //   * a chunk ends with a plain read-add-write of the lane's sums into the WAVE'S OWN LDS row of that splat (LDS
 //     float atomics cost ~160 cycles per instruction on gfx950 and are avoided), and a pass over the staged batch
-//     ends with ONE 64-byte, line-aligned row of global float atomics per (8x8 patch, splat): 16 lanes commit the
-//     16 floats of moments[id] in one instruction.
+//     ends with ONE 64-byte, line-aligned row of global float atomics per (8x8 patch, splat): seven rows of nine
+//     sums per wave instruction.
 //
 // VALU work per (sub-patch, splat) hit is ~16 pixel steps x ~46 instructions / (lanes filled) ~= 16 wave
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
@@ -506,21 +506,30 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         }
       }
 
-      // ---- commit the pass: ONE 64-byte row of global float atomics per (patch, splat), 16 lanes per row -----
+      // ---- commit the pass: ONE 64-byte, line-aligned row of global float atomics per (patch, splat) ------------
       wave_lds_fence();
-      for (int i = lane; i < pcount * MOMENT_ROW; i += 64) {
-        const int e = i >> 4, k = i & 15;
-        if (k < NACC) {
-          const float v = s_acc[wave][e][k];
-          if (v != 0.0f) {
-            const size_t word = (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k;
-            if (rp.deterministic)
-              __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
-                                     (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
-                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-              atomic_add_noret(moments + word, v);
-            s_acc[wave][e][k] = 0.0f;
+      // ROWS_PER rows of NACC sums per instruction (7 x 9 = 63 lanes; 5 x 11 with heuristics): the LDS reads sweep
+      // the wave's accumulator block linearly and the loop runs pcount / 7 times (16 lanes per row, 9 of them with
+      // data, ran pcount / 4 times: 1.45 -> 1.37 ms on config D; the atomics themselves are 0.10 ms of instruction
+      // rate + 0.04 ms of misses: 1.33 ms when every row lands in a 16 MB window, 1.21 ms without the commit)
+      {
+        constexpr int ROWS_PER = 64 / NACC;
+        const int sub_row = lane / NACC, k = lane - sub_row * NACC;
+        const bool lane_used = sub_row < ROWS_PER;
+        for (int e0 = 0; e0 < pcount; e0 += ROWS_PER) {
+          const int e = e0 + sub_row;
+          if (lane_used && e < pcount) {
+            const float v = s_acc[wave][e][k];
+            if (v != 0.0f) {
+              const size_t word = (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k;
+              if (rp.deterministic)
+                __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
+                                       (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else
+                atomic_add_noret(moments + word, v);
+              s_acc[wave][e][k] = 0.0f;
+            }
           }
         }
       }

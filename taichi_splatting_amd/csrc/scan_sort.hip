@@ -446,9 +446,11 @@ static int radix_sort_passes(const First first, KeyT* keys_out, int32_t* vals_ou
   const int passes = (end_bit - begin_bit + 7) / 8;
   const dim3 grid((unsigned)blocks), block(RS_THREADS);
   PlainPairs<KeyT> src{nullptr, nullptr};
-  for (int p = 0; p < passes; ++p) {
-    const int shift = begin_bit + 8 * p;
-    const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+  // digits of equal width (14 tile bits = 7 + 7, not 8 + 6): fewer bins -> longer contiguous runs in the scatter
+  const int total_bits = end_bit - begin_bit, base_bits = total_bits / passes, wide = total_bits % passes;
+  int shift = begin_bit;
+  for (int p = 0; p < passes; shift += base_bits + (p < wide ? 1 : 0), ++p) {
+    const int bits = base_bits + (p < wide ? 1 : 0);
     const unsigned mask = (1u << bits) - 1u;
     const bool to_out = ((passes - 1 - p) % 2) == 0;
     KeyT* dst_k = to_out ? keys_out : keys_alt;
