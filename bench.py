@@ -25,7 +25,6 @@ HIP graph (``graph_ms_per_step``, timed in a child process) and the tile 8 / 16 
 Prints ONE JSON line on rank 0 (metric, roofline of the dominant kernel, CPU-oracle baseline).
 """
 import argparse
-import gc
 import json
 import os
 import sys
@@ -342,18 +341,16 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
   # The interpreter's cyclic collector is parked for the timed region: a generation-2 pass over torch's ~10^6 tracked
   # objects stops the host for 35-45 ms — ten frames — once every couple of hundred frames, and the GPU queue holds
   # three (tools/host_overhead.py: frame intervals median 3.40 ms, max 44 ms with the collector, 11 ms without).
-  # Nothing is skipped: reference counting still frees every tensor of a frame as the frame ends.
-  gc.collect()
-  gc.freeze()
-  gc.disable()
-  barrier()
-  syncs0 = frame_mod.host_syncs + frame_mod.point_syncs
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    run()
-  torch.cuda.synchronize()
-  mine = time.perf_counter() - t0            # this rank's own time (before waiting for the slowest)
-  gc.enable()
+  # Nothing is skipped: reference counting still frees every tensor of a frame as the frame ends
+  # (taichi_splatting_amd.frame.parked_gc, what a training loop on this back end would wrap its epoch in).
+  with frame_mod.parked_gc():
+    barrier()
+    syncs0 = frame_mod.host_syncs + frame_mod.point_syncs
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      run()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0            # this rank's own time (before waiting for the slowest)
   comm['host_syncs_per_step'] = (frame_mod.host_syncs + frame_mod.point_syncs - syncs0) / max(args.steps, 1)
   barrier()
   elapsed = time.perf_counter() - t0
@@ -652,13 +649,13 @@ def tile_step_ms(g, cam, tile, steps):
   while time.perf_counter() - t_spin < 0.3:
     step()
   torch.cuda.synchronize()
-  gc.collect(); gc.disable()                 # as in the timed region of run_mode
-  t0 = time.perf_counter()
-  for _ in range(steps):
-    step()
-  torch.cuda.synchronize()
-  ms = (time.perf_counter() - t0) / steps * 1e3
-  gc.enable()
+  from taichi_splatting_amd import frame
+  with frame.parked_gc():                    # as in the timed region of run_mode
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
   g.requires_grad_(False)
   for t in leaves:
     t.grad = None

@@ -81,3 +81,26 @@ def test_frame_layout_query_and_dispatch_without_a_gpu():
   assert lib.ms_frame_layout_query(ctypes.byref(d), ctypes.byref(lay)) == -2
   d.f = 3; d.projected_input = 1  # projected input cannot carry SH
   assert lib.ms_frame_layout_query(ctypes.byref(d), ctypes.byref(lay)) == -1
+
+
+def test_parked_gc_restores_the_collector():
+  """frame.parked_gc: the collector is off inside the block and back to its previous state after it, also on error"""
+  import gc
+  from taichi_splatting_amd import frame
+  assert gc.isenabled()
+  with frame.parked_gc():
+    assert not gc.isenabled()
+  assert gc.isenabled()
+  try:
+    with frame.parked_gc():
+      raise ValueError("boom")
+  except ValueError:
+    pass
+  assert gc.isenabled()
+  gc.disable()
+  try:
+    with frame.parked_gc():
+      pass
+    assert not gc.isenabled()            # it was off before: stays off
+  finally:
+    gc.enable()
