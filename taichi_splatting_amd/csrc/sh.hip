@@ -2,8 +2,14 @@
 //
 // One thread per visible gaussian; params rows are (F, D) contiguous (D = (deg+1)^2), i.e. 192 B
 // per gaussian for RGB degree 3: a pure HBM stream, gathered through the int64 index list.
+#include <stdlib.h>
+
 #include "common.h"
 #include "frame_internal.h"
+
+#ifndef MS_SH_ROWS_BLOCKS
+#define MS_SH_ROWS_BLOCKS 4096
+#endif
 
 namespace ms {
 
@@ -38,6 +44,71 @@ sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
 #pragma unroll
     for (int d = 0; d < D; ++d) acc += Y[d] * p[c * D + d];
     out[i * f + c] = t_clamp(acc + T(0.5), T(0), T(1));
+  }
+}
+
+// Frame executor, float32 RGB degree 3 (the headline configuration): the parameter rows of a wave's 64 consecutive
+// gaussians are ONE contiguous 12 KB block, read as twelve fully coalesced 128-bit loads per lane (1 KB per wave
+// instruction) instead of 64 lanes each walking its own 192-byte row — that walk lives off L1 / L2 hits between the
+// lane's four visits of a 64-byte line and streamed 4.6-5.0 TB/s where the chip reads 6.2-7.1 (tools/ubench_stream.hip).
+// A lane then holds piece q = 64 r + lane of the block = coefficients 4k..4k+3 of channel c of gaussian j (q = 12 j + k):
+// it takes the four basis values of gaussian j from LDS (written by lane j a moment ago), forms a partial dot
+// product, and the four pieces of a (gaussian, channel) — an aligned quad of lanes — are summed with two quad_perm DPP
+// adds; the quad's first lane clamps and stores (16 consecutive floats per store instruction).  Rows of culled
+// gaussians are not read.  The summation order differs from sh_fwd_kernel's (4 x 4 instead of 16 in a row): colours
+// agree to rounding, which is what both are held to against the oracle.
+__global__ void __launch_bounds__(256)
+sh_fwd_rows_deg3_kernel(const float* __restrict__ params, const float* __restrict__ positions,
+                        const float* __restrict__ cam_pos, const float* __restrict__ cull_depth, int64_t n,
+                        float* __restrict__ out) {
+  constexpr int D = 16, PIECES = 12, YS = 20;      // YS: 16-byte aligned rows, 4 lanes apart never on the same banks
+  typedef float vec4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float s_Y[4][64 * YS];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const float cx = cam_pos[0], cy = cam_pos[1], cz = cam_pos[2];
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < n; base += (int64_t)gridDim.x * 256) {
+    const int count = (n - base) < 64 ? (int)(n - base) : 64;
+    const int64_t i = base + lane;
+    const bool vis = lane < count && (!cull_depth || cull_depth[i] > 0.0f);
+    const unsigned long long visible = __ballot(vis);
+    // the block's pieces first: twelve independent loads in flight while the basis is evaluated
+    const vec4* src = reinterpret_cast<const vec4*>(params + base * (3 * D));
+    vec4 piece[PIECES];
+#pragma unroll
+    for (int r = 0; r < PIECES; ++r) {
+      const int q = r * 64 + lane, j = q / PIECES;
+      const bool on = j < count && ((visible >> j) & 1ull);
+      piece[r] = on ? __builtin_nontemporal_load(src + q) : vec4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (vis) {
+      const float dx = positions[i * 3 + 0] - cx, dy = positions[i * 3 + 1] - cy, dz = positions[i * 3 + 2] - cz;
+      const float len = t_sqrt(dx * dx + dy * dy + dz * dz);
+      float Y[D];
+      sh_basis<float, 3>(dx / len, dy / len, dz / len, Y);
+#pragma unroll
+      for (int d = 0; d < D; d += 4)
+        *reinterpret_cast<vec4*>(&s_Y[wave][lane * YS + d]) = vec4{Y[d], Y[d + 1], Y[d + 2], Y[d + 3]};
+    }
+    // LDS traffic stays inside the wave; the fences keep the compiler from forwarding per-thread values
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* dst = out + base * 3;
+#pragma unroll
+    for (int r = 0; r < PIECES; ++r) {
+      const int q = r * 64 + lane, j = q / PIECES, k = q - j * PIECES;
+      const bool on = j < count && ((visible >> j) & 1ull);
+      const int d0 = (k & 3) * 4;                       // k = 4 c + (piece of the channel)
+      const vec4 y = on ? *reinterpret_cast<const vec4*>(&s_Y[wave][j * YS + d0]) : vec4{0.f, 0.f, 0.f, 0.f};
+      float acc = piece[r].x * y.x + piece[r].y * y.y + piece[r].z * y.z + piece[r].w * y.w;
+      acc += dpp_f32<0xB1>(0.f, acc);                   // quad_perm:[1,0,3,2]
+      acc += dpp_f32<0x4E>(0.f, acc);                   // quad_perm:[2,3,0,1]
+      // q / 4 = 3 j + c: the quad's first lane writes colour c of gaussian j (0 for a culled one, sh_fwd_kernel's)
+      if ((lane & 3) == 0 && j < count) dst[q >> 2] = on ? t_clamp(acc + 0.5f, 0.0f, 1.0f) : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 
@@ -243,6 +314,15 @@ static void launch_sh_fwd_inplace(const void* params, const void* positions, con
 int sh_fwd_inplace_launch(const void* params, const void* positions, const void* depth, const void* cam_pos,
                           int64_t n, int f, int degree, void* out, int dtype, hipStream_t s) {
   if (n == 0) return 0;
+  static const bool rows_off = [] { const char* e = getenv("MS_SH_FWD"); return e && e[0] == 'w'; }();   // "walk": the per-lane row walk
+  if (dtype == MS_F32 && f == 3 && degree == 3 && !rows_off && (reinterpret_cast<uintptr_t>(params) & 15) == 0) {
+    int64_t blocks = div_up(n, 256);
+    if (blocks > MS_SH_ROWS_BLOCKS) blocks = MS_SH_ROWS_BLOCKS;       // grid-stride: a resident grid streams best
+    sh_fwd_rows_deg3_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const float*)params, (const float*)positions,
+                                                                        (const float*)cam_pos, (const float*)depth, n,
+                                                                        (float*)out);
+    return 0;
+  }
   if (dtype == MS_F32) launch_sh_fwd_inplace<float>(params, positions, depth, cam_pos, n, f, degree, out, s);
   else launch_sh_fwd_inplace<double>(params, positions, depth, cam_pos, n, f, degree, out, s);
   return 0;

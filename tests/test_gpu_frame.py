@@ -70,14 +70,17 @@ def test_frame_equals_modular_f32(use_sh, degree, tile):
   torch.manual_seed(0)
   G = torch.randn(200, 320, 3, device=DEV)
   (rf, gf), (rl, gl) = render_both(g, cam, cfg, use_sh, loss=lambda r: (r.image * G).sum())
-  assert torch.equal(rf.image, rl.image)
+  # float32 RGB degree 3: the frame's SH kernel (sh_fwd_rows_deg3_kernel) sums a colour's 16 terms as 4 x 4, the
+  # modular one in a row — colours agree to rounding, everything that does not depend on them bit for bit
+  same = torch.equal if degree != 3 else (lambda a, b: bool(torch.allclose(a, b, rtol=0, atol=2e-6)))
+  assert same(rf.image, rl.image)
   assert torch.equal(rf.image_weight, rl.image_weight)
   assert_grads_close(gf, gl)
   # the lazily compacted points are the modular path's
   assert torch.equal(rf.points.idx, rl.points.idx)
   assert torch.equal(rf.points.gaussians2d, rl.points.gaussians2d)
   assert torch.equal(rf.points.depths, rl.points.depths)
-  assert torch.equal(rf.points.features, rl.points.features)
+  assert same(rf.points.features, rl.points.features)
 
 
 def test_frame_with_culled_gaussians_and_camera_grads():
@@ -113,6 +116,19 @@ def test_frame_with_culled_gaussians_and_camera_grads():
   assert torch.allclose(pf, pl, rtol=2e-3, atol=1e-3 * float(pl.abs().max()))
 
 
+@pytest.mark.parametrize('n', [1, 63, 64 * 37 + 13, 20000])
+def test_frame_sh_degree3_rows_kernel(n):
+  """sh_fwd_rows_deg3_kernel (coalesced block loads, quad sums) against the modular evaluate_sh_at on the visible set:
+  partial last block, culled gaussians in the middle of a block (their rows are skipped, their colours unused)"""
+  g, cam = make_scene(n, (256, 256), seed=n % 97, sh_degree=3, margin=0.6)
+  (rf, _), (rl, _) = render_both(g, cam, RasterConfig(), True)
+  assert torch.equal(rf.points.idx, rl.points.idx)
+  assert rf.points.features.shape == rl.points.features.shape
+  if rl.points.features.numel():
+    assert float((rf.points.features - rl.points.features).abs().max()) < 1e-6
+  assert torch.allclose(rf.image, rl.image, rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize('antialias', [False, True])
 def test_frame_equals_modular_f64(antialias):
   g, cam = make_scene(3000, (160, 96), seed=11, sh_degree=1, dtype=torch.float64, margin=0.3)
@@ -137,7 +153,7 @@ def test_frame_visibility_heuristics_median_depth16():
   g, cam = make_scene(15000, (256, 192), seed=9, sh_degree=3)
   cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
   (rf, gf), (rl, gl) = render_both(g, cam, cfg, True, loss=lambda r: r.image.sum(), render_median_depth=True, use_depth16=True)
-  assert torch.equal(rf.image, rl.image)
+  assert torch.allclose(rf.image, rl.image, rtol=0, atol=2e-6)        # degree-3 colours: equal to rounding (see above)
   assert torch.equal(rf.median_depth_image, rl.median_depth_image)
   assert torch.allclose(rf.points.visibility, rl.points.visibility, rtol=1e-4, atol=1e-5)
   for a, b in ((rf.points.prune_cost, rl.points.prune_cost), (rf.points.split_score, rl.points.split_score)):
@@ -251,7 +267,7 @@ def test_frame_under_hip_graph_capture():
     want = render_gaussians(g, cam, cfg, use_sh=True).image
   finally:
     frame.USE_FRAME = True
-  assert torch.equal(r.image, want)
+  assert torch.allclose(r.image, want, rtol=0, atol=2e-6)      # degree-3 colours of the two SH kernels: equal to rounding
   assert not frame.frame_status(r)['overflow']
 
 
