@@ -8,7 +8,7 @@
 #include "frame_internal.h"
 
 #ifndef MS_SH_ROWS_BLOCKS
-#define MS_SH_ROWS_BLOCKS 4096
+#define MS_SH_ROWS_BLOCKS 16384
 #endif
 
 namespace ms {
