@@ -93,20 +93,26 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->scratch_k_bytes = scratch_k.off;
 }
 
-// K (the scan's total) -> counters[0] and the caller's pinned word
-__global__ void frame_k_kernel(const int32_t* __restrict__ total, int32_t* __restrict__ counters, int32_t* __restrict__ k_host) {
-  const int32_t k = *total;
-  counters[0] = k;
-  if (k_host) *k_host = k;
-}
-
-// live K against the capacity of this call's overlap buffers: 0 (nothing is emitted, sorted or ranged) on overflow —
-// an int32 total that wrapped negative counts as overflow
-__global__ void frame_k_limit_kernel(int32_t* __restrict__ counters, int32_t capacity) {
-  const int32_t k = counters[0];
-  const bool ok = k >= 0 && k <= capacity;
-  counters[1] = ok ? k : 0;
-  counters[2] = ok ? 0 : 1;
+// What ms_frame_map_raster needs before its first real kernel, in ONE launch (a launch boundary costs ~5 us on this
+// chip whatever the kernel does; K itself is written to counters[0] and the caller's pinned word by the last block
+// of the overlap scan):
+//   * live K against the capacity of this call's overlap buffers: 0 (nothing is emitted, sorted or ranged) on
+//     overflow — an int32 total that wrapped negative counts as overflow;
+//   * the camera position for the SH colours (cam_out != NULL);
+//   * the zero fill of the tile ranges (empty tiles stay [0, 0), tile_mapper.py:93-112).
+template <typename T>
+__global__ void __launch_bounds__(256)
+frame_prepare_kernel(int32_t* __restrict__ counters, int32_t capacity, const T* __restrict__ Tcw, T* __restrict__ cam_out,
+                     int32_t* __restrict__ ranges, int64_t range_words) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < range_words) ranges[i] = 0;
+  if (i == 0) {
+    const int32_t k = counters[0];
+    const bool ok = k >= 0 && k <= capacity;
+    counters[1] = ok ? k : 0;
+    counters[2] = ok ? 0 : 1;
+    if (cam_out) camera_position_solve(Tcw, cam_out);
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -157,7 +163,9 @@ static int frame_project_impl(const ms_frame_desc* desc, const ms_frame_inputs* 
   }
   if (!in->feature) { set_error("%s: feature is null", who); return MS_ERR_BAD_ARG; }
   if (projection) {
-    if (d.sh_degree >= 0)
+    // (projection alone = ms_frame_project_count: the camera position is then made by ms_frame_map_raster's prepare
+    // kernel, next to the K limit)
+    if (d.sh_degree >= 0 && colours)
       MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
     MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
                           d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
@@ -228,8 +236,7 @@ extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_
                        sorted_keys, order, sn + L.tmp_n, s);
   tile_count_launch(points_f32, order, cull ? sorted_keys : nullptr, d.n, g.w_pad, g.h_pad, d.raster.tile_size,
                     (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counts, (float*)(sn + L.ordered_points), s);
-  exclusive_scan_launch(counts, d.n, cum, nullptr, sn + L.tmp_n, s);
-  frame_k_kernel<<<1, 1, 0, s>>>(cum + d.n, counters, k_host);
+  exclusive_scan_launch(counts, d.n, cum, k_host, sn + L.tmp_n, s, counters);      // K -> counters[0] and *k_host
   MS_CHECK_LAUNCH();
   if (k_event) MS_CHECK_HIP(hipEventRecord((hipEvent_t)k_event, s));
   return 0;
@@ -253,7 +260,18 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   int32_t* ranges = (int32_t*)(kn + L.tile_ranges);
   int32_t* o2p = (int32_t*)(kk + L.overlap_to_point);
 
-  frame_k_limit_kernel<<<1, 1, 0, s>>>(counters, (int32_t)d.k_capacity);
+  {
+    const bool want_cam = !d.projected_input && d.sh_degree >= 0 && d.n > 0;
+    if (want_cam) MS_CHECK_ARG(in->T_camera_world != nullptr, "T_camera_world is null");
+    const int64_t words = (int64_t)g.num_tiles * 2;
+    const dim3 grid((unsigned)(words > 0 ? div_up(words, 256) : 1)), block(256);
+    if (d.dtype == MS_F64)
+      frame_prepare_kernel<double><<<grid, block, 0, s>>>(counters, (int32_t)d.k_capacity, (const double*)in->T_camera_world,
+                                                          want_cam ? (double*)(kn + L.camera_position) : nullptr, ranges, words);
+    else
+      frame_prepare_kernel<float><<<grid, block, 0, s>>>(counters, (int32_t)d.k_capacity, (const float*)in->T_camera_world,
+                                                         want_cam ? (float*)(kn + L.camera_position) : nullptr, ranges, words);
+  }
   if (!d.projected_input) MS_TRY(frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_map_raster"));
   if (d.n > 0 && d.k_capacity > 0) {
     MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
@@ -264,9 +282,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
                              (const int32_t*)(sn + L.cum), d.n, g.w_pad, g.h_pad, d.raster.tile_size,
                              (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counters + 1, keys, values, s);
     sort_pairs_u32_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, g.tile_bits, sk + L.tmp_k, s);
-    MS_TRY(find_ranges_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s));
-  } else {
-    MS_TRY(find_ranges_dev_launch(nullptr, 0, nullptr, g.num_tiles, ranges, s));
+    MS_TRY(find_ranges_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s, true));
   }
   MS_CHECK_LAUNCH();
 

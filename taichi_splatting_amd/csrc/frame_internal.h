@@ -12,11 +12,41 @@ namespace ms {
 // count / emit kernels to skip the row
 constexpr uint32_t CULLED_DEPTH_KEY = 0xffffffffu;
 
+// Translation column of inverse(T_camera_world) (reference perspective/params.py:62-65 computes
+// torch.inverse(T)[0:3, 3]): Gauss-Jordan with partial pivoting in double, one thread.  Shared by ms_camera_position
+// (projection.hip) and the frame executor's prepare kernel (frame.hip); contraction is off inside so that both
+// translation units round identically.
+template <typename T>
+__device__ inline void camera_position_solve(const T* __restrict__ m, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  double a[4][5];
+  for (int r = 0; r < 4; ++r) {
+    for (int c = 0; c < 4; ++c) a[r][c] = (double)m[r * 4 + c];
+    a[r][4] = r == 3 ? 1.0 : 0.0;                     // solve T x = e_3: x = 4th column of the inverse
+  }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
+    for (int c = 0; c < 5; ++c) { const double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
+    const double inv = 1.0 / a[col][col];
+    for (int c = 0; c < 5; ++c) a[col][c] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == col) continue;
+      const double fct = a[r][col];
+      for (int c = 0; c < 5; ++c) a[r][c] -= fct * a[col][c];
+    }
+  }
+  for (int k = 0; k < 3; ++k) out[k] = (T)a[k][4];
+}
+
 // ---- scan_sort.hip ----------------------------------------------------------------------------------------------
 size_t scan_tmp_size(int64_t n);
 size_t sort_tmp_size(int64_t n, int key_bytes);
-// exclusive scan of n int32 into out[0..n] (out[n] = total)
-void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s);
+// exclusive scan of n int32 into out[0..n] (out[n] = total); the total also goes to *total_host (pinned) and
+// *total_copy (device) when given
+void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s,
+                           int32_t* total_copy = nullptr);
 // ms_depth_argsort with `cull`: depth <= 0 marks a culled gaussian (key CULLED_DEPTH_KEY)
 void depth_argsort_launch(const void* depth, int64_t n, int depth16, double ndc_near, double ndc_far, int dtype,
                           int cull, uint32_t* out_sorted_keys, int32_t* out_order, char* tmp, hipStream_t s);
@@ -24,9 +54,10 @@ void depth_argsort_launch(const void* depth, int64_t n, int depth16, double ndc_
 // the live count is *n_dev (<= capacity)
 void sort_pairs_u32_dev_launch(const uint32_t* keys_in, const int32_t* vals_in, uint32_t* keys_out, int32_t* vals_out,
                                int64_t capacity, const int32_t* n_dev, int end_bit, char* tmp, hipStream_t s);
-// per-tile [first, last + 1) ranges of the sorted tile ids; writes every entry (zero fill included)
+// per-tile [first, last + 1) ranges of the sorted tile ids; writes every entry (zero fill included unless the caller
+// has `zeroed` the array on the stream already)
 int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
-                           int32_t* out_ranges, hipStream_t s);
+                           int32_t* out_ranges, hipStream_t s, bool zeroed = false);
 
 // ---- mapper.hip -------------------------------------------------------------------------------------------------
 void tile_count_launch(const float* points7, const int32_t* order, const uint32_t* cull_keys, int64_t v, int image_w,

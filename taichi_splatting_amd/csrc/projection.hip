@@ -6,6 +6,7 @@
 // culling decisions (in_view) are float comparisons shared with the oracle: no FMA contraction
 #pragma clang fp contract(off)
 #include "common.h"
+#include "frame_internal.h"
 
 namespace ms {
 
@@ -225,25 +226,7 @@ extern "C" int ms_project_bwd(const void* position, const void* log_scaling, con
 namespace ms {
 template <typename T>
 __global__ void camera_position_kernel(const T* __restrict__ m, T* __restrict__ out) {
-  double a[4][5];
-  for (int r = 0; r < 4; ++r) {
-    for (int c = 0; c < 4; ++c) a[r][c] = (double)m[r * 4 + c];
-    a[r][4] = r == 3 ? 1.0 : 0.0;                     // solve T x = e_3: x = 4th column of the inverse
-  }
-  for (int col = 0; col < 4; ++col) {
-    int piv = col;
-    for (int r = col + 1; r < 4; ++r)
-      if (fabs(a[r][col]) > fabs(a[piv][col])) piv = r;
-    for (int c = 0; c < 5; ++c) { const double t = a[col][c]; a[col][c] = a[piv][c]; a[piv][c] = t; }
-    const double inv = 1.0 / a[col][col];
-    for (int c = 0; c < 5; ++c) a[col][c] *= inv;
-    for (int r = 0; r < 4; ++r) {
-      if (r == col) continue;
-      const double fct = a[r][col];
-      for (int c = 0; c < 5; ++c) a[r][c] -= fct * a[col][c];
-    }
-  }
-  for (int k = 0; k < 3; ++k) out[k] = (T)a[k][4];
+  camera_position_solve(m, out);
 }
 }  // namespace ms
 

@@ -89,7 +89,7 @@ scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __res
 // single block: exclusive scan of block_sums in place; writes the grand total
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_spine_kernel(int32_t* __restrict__ block_sums, int64_t num_blocks, int32_t* __restrict__ total_out,
-                  int32_t* __restrict__ total_host) {
+                  int32_t* __restrict__ total_host, int32_t* __restrict__ total_copy = nullptr) {
   __shared__ int lds[4];
   int carry = 0;
   for (int64_t base = 0; base < num_blocks; base += SCAN_THREADS) {
@@ -102,6 +102,7 @@ scan_spine_kernel(int32_t* __restrict__ block_sums, int64_t num_blocks, int32_t*
   }
   if (threadIdx.x == 0) {
     *total_out = carry;
+    if (total_copy) *total_copy = carry;
     if (total_host) *total_host = carry;
   }
 }
@@ -134,7 +135,8 @@ constexpr int64_t SCAN_SELF_MAX_BLOCKS = 8192;
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_downsweep_self_kernel(const int32_t* __restrict__ in, int64_t n, const int32_t* __restrict__ block_sums,
-                           int32_t* __restrict__ out, int32_t* __restrict__ total_host) {
+                           int32_t* __restrict__ out, int32_t* __restrict__ total_host,
+                           int32_t* __restrict__ total_copy = nullptr) {
   __shared__ int lds[4];
   int before = 0;
   for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += block_sums[j];
@@ -158,6 +160,7 @@ scan_downsweep_self_kernel(const int32_t* __restrict__ in, int64_t n, const int3
   store_items(out, base, n, vals);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     out[n] = block_prefix + total;
+    if (total_copy) *total_copy = block_prefix + total;         // frame executor: counters[0]
     if (total_host) *total_host = block_prefix + total;
   }
 }
@@ -167,15 +170,15 @@ static size_t scan_tmp_bytes(int64_t n) { return align_up((size_t)div_up(n > 0 ?
 // out has n + 1 entries (out[n] = total).  in and out may NOT alias unless identical ranges are
 // intended (in == out is allowed: every block reads its tile before writing it).
 static int exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp,
-                              hipStream_t s) {
+                              hipStream_t s, int32_t* total_copy = nullptr) {
   const int64_t blocks = div_up(n, SCAN_TILE);
   int32_t* block_sums = (int32_t*)tmp;
   scan_block_sums_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums);
   if (blocks <= SCAN_SELF_MAX_BLOCKS) {
-    scan_downsweep_self_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out, total_host);
+    scan_downsweep_self_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out, total_host, total_copy);
     return 0;
   }
-  scan_spine_kernel<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(block_sums, blocks, out + n, total_host);
+  scan_spine_kernel<<<dim3(1), dim3(SCAN_THREADS), 0, s>>>(block_sums, blocks, out + n, total_host, total_copy);
   scan_downsweep_kernel<<<dim3((unsigned)blocks), dim3(SCAN_THREADS), 0, s>>>(in, n, block_sums, out);
   return 0;
 }
@@ -516,8 +519,9 @@ find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, const int32_t* __re
 size_t scan_tmp_size(int64_t n) { return scan_tmp_bytes(n); }
 size_t sort_tmp_size(int64_t n, int key_bytes) { return sort_tmp_layout(n, key_bytes).total; }
 
-void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s) {
-  exclusive_scan_i32(in, n, out, total_host, tmp, s);
+void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s,
+                           int32_t* total_copy) {
+  exclusive_scan_i32(in, n, out, total_host, tmp, s, total_copy);
 }
 
 void depth_argsort_launch(const void* depth, int64_t n, int depth16, double ndc_near, double ndc_far, int dtype,
@@ -535,8 +539,8 @@ void sort_pairs_u32_dev_launch(const uint32_t* keys_in, const int32_t* vals_in, 
 }
 
 int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
-                           int32_t* out_ranges, hipStream_t s) {
-  if (num_tiles > 0) MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), s));
+                           int32_t* out_ranges, hipStream_t s, bool zeroed) {
+  if (num_tiles > 0 && !zeroed) MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), s));
   if (capacity > 0)
     find_ranges_kernel<uint32_t><<<dim3((unsigned)div_up(capacity, 256)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, 0, num_tiles, out_ranges);
   return 0;
