@@ -225,30 +225,37 @@ template <typename KeyT, typename Source>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_upsweep_kernel(const Source src, int64_t n, const int32_t* __restrict__ n_dev, int shift, unsigned mask,
                      int32_t* __restrict__ hist, int64_t num_blocks) {
-  __shared__ unsigned cnt[RS_WAVES][RS_RADIX];
+  // RS_COPIES counter sets per wave (lane & 3 picks one): the last pass of the depth sort sees a handful of distinct
+  // digits (sign + high exponent bits), and 64 lanes adding to one LDS word are served one after the other
+  // (25 us against 11 us for the other passes over the same 6 M keys with a single set)
+  constexpr int RS_COPIES = 4;
+  __shared__ unsigned cnt[RS_WAVES][RS_COPIES][RS_RADIX];
   if (n_dev) n = *n_dev;        // live count on the device; the grid covers the capacity (idle blocks write zeros)
-  for (int i = threadIdx.x; i < RS_WAVES * RS_RADIX; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < RS_WAVES * RS_COPIES * RS_RADIX; i += RS_THREADS) (&cnt[0][0][0])[i] = 0;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
+  unsigned* mine = cnt[wave][lane & (RS_COPIES - 1)];
   const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS + lane;
   if ((int64_t)(blockIdx.x + 1) * RS_TILE <= n) {        // every item of the block exists: no bounds checks
     KeyT k[RS_ROUNDS];
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; ++j) k[j] = src.key(base + j * 64);
 #pragma unroll
-    for (int j = 0; j < RS_ROUNDS; ++j) atomicAdd(&cnt[wave][key_digit(k[j], shift, mask)], 1u);
+    for (int j = 0; j < RS_ROUNDS; ++j) atomicAdd(&mine[key_digit(k[j], shift, mask)], 1u);
   } else {
 #pragma unroll 4
     for (int j = 0; j < RS_ROUNDS; ++j) {
       const int64_t i = base + j * 64;
-      if (i < n) atomicAdd(&cnt[wave][key_digit(src.key(i), shift, mask)], 1u);
+      if (i < n) atomicAdd(&mine[key_digit(src.key(i), shift, mask)], 1u);
     }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < RS_RADIX; d += RS_THREADS) {
     unsigned t = 0;
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) t += cnt[w][d];
+    for (int w = 0; w < RS_WAVES; ++w)
+#pragma unroll
+      for (int c = 0; c < RS_COPIES; ++c) t += cnt[w][c][d];
     hist[(int64_t)d * num_blocks + blockIdx.x] = (int32_t)t;
   }
 }
