@@ -522,6 +522,34 @@ find_ranges_kernel(const KeyT* __restrict__ keys, int64_t k, const int32_t* __re
   }
 }
 
+// frame executor: u32 tile ids (shift 0), four keys per thread from one 128-bit load + the key after them
+__global__ void __launch_bounds__(256)
+find_ranges4_kernel(const uint32_t* __restrict__ keys, int64_t capacity, const int32_t* __restrict__ k_dev,
+                    int64_t num_tiles, int32_t* __restrict__ ranges) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t k = k_dev ? (int64_t)*k_dev : capacity;
+  if (i0 >= k) return;
+  uint32_t t[5];
+  if (i0 + 4 < k) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w; t[4] = keys[i0 + 4];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) t[j] = i0 + j < k ? keys[i0 + j] : 0xffffffffu;      // 0xffffffff: no next key
+  }
+  if (i0 == 0 && (int64_t)t[0] < num_tiles) ranges[(int64_t)t[0] * 2 + 0] = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = i0 + j;
+    if (i >= k) break;
+    const int64_t tile = t[j], next = (i + 1 < k) ? (int64_t)t[j + 1] : -1;
+    if (tile != next) {
+      if (tile < num_tiles) ranges[tile * 2 + 1] = (int32_t)(i + 1);
+      if (next >= 0 && next < num_tiles) ranges[next * 2 + 0] = (int32_t)(i + 1);
+    }
+  }
+}
+
 // ---- launchers for the frame executor (frame_internal.h) ----------------------------------------------------------
 size_t scan_tmp_size(int64_t n) { return scan_tmp_bytes(n); }
 size_t sort_tmp_size(int64_t n, int key_bytes) { return sort_tmp_layout(n, key_bytes).total; }
@@ -549,7 +577,7 @@ int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const 
                            int32_t* out_ranges, hipStream_t s, bool zeroed) {
   if (num_tiles > 0 && !zeroed) MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), s));
   if (capacity > 0)
-    find_ranges_kernel<uint32_t><<<dim3((unsigned)div_up(capacity, 256)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, 0, num_tiles, out_ranges);
+    find_ranges4_kernel<<<dim3((unsigned)div_up(capacity, 1024)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, num_tiles, out_ranges);
   return 0;
 }
 
