@@ -268,12 +268,24 @@ radix_row_scan_kernel(int32_t* __restrict__ hist, int64_t num_blocks, int32_t* _
   __shared__ int lds[4];
   int32_t* row = hist + (int64_t)blockIdx.x * num_blocks;
   int carry = 0;
-  for (int64_t base = 0; base < num_blocks; base += SCAN_THREADS) {
-    const int64_t i = base + threadIdx.x;
-    const int v = i < num_blocks ? row[i] : 0;
+  // SCAN_TILE entries per round, 16 consecutive ones per thread: a row of config D's tile sort (3100 blocks) is one
+  // round with two barriers instead of thirteen rounds of one entry per thread (11.6 -> ~6 us per launch)
+  for (int64_t base = 0; base < num_blocks; base += SCAN_TILE) {
+    const int64_t mine = base + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int vals[SCAN_ITEMS];
+    load_items(row, mine, num_blocks, vals);
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) s += vals[k];
     int total;
-    const int ex = block_exclusive_scan(v, lds, &total);
-    if (i < num_blocks) row[i] = carry + ex;
+    int prefix = carry + block_exclusive_scan(s, lds, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+      const int v = vals[k];
+      vals[k] = prefix;
+      prefix += v;
+    }
+    store_items(row, mine, num_blocks, vals);
     carry += total;
   }
   if (threadIdx.x == 0) digit_totals[blockIdx.x] = carry;
