@@ -2,7 +2,7 @@
 """Summarise a rocprofv3 rocpd database (``*_results.db``) into a per-kernel table
 (calls, total / average / min / max duration, share) — the equivalent of ``--stats`` CSV output.
 
-    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--steps K] > profiles/r01_xxx.txt
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--steps K] [--last-steps S [--anchor kernel]] > profiles/r01_xxx.txt
 """
 import re
 import sqlite3
@@ -24,7 +24,15 @@ def main():
   cur = con.cursor()
   cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
   name_col = 'name' if 'name' in cols else 'kernel_name'
-  rows = cur.execute(f"select {name_col}, start, end from kernels").fetchall()
+  rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
+  if '--last-steps' in sys.argv:
+    # steady state only: keep the dispatches from the S-th last launch of the anchor kernel (first kernel of a step) on
+    last = int(sys.argv[sys.argv.index('--last-steps') + 1])
+    anchor = sys.argv[sys.argv.index('--anchor') + 1] if '--anchor' in sys.argv else 'project_fwd_kernel'
+    marks = [i for i, r in enumerate(rows) if anchor in r[0]]
+    if len(marks) >= last:
+      rows = rows[marks[-last]:]
+      steps = last
   agg = {}
   for name, s, e in rows:
     a = agg.setdefault(name, [0, 0, 1 << 62, 0])
