@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_VERSION 300  /* 0.3.0: frame executor */
+#define MS_VERSION 301  /* 0.3.1: frame executor; row-strided 2D-boundary gradients (ms_frame_grads.boundary_stride, ms_strip_return_rows) */
 
 enum { MS_F32 = 0, MS_F64 = 1 };
 
@@ -307,6 +307,11 @@ typedef struct ms_frame_grads {
   void *grad_points7, *grad_colours;   /* moments path: optional stores of the summed 2D-boundary gradients */
   void *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit, *grad_feature, *grad_camera;
   void* point_heuristic;           /* (n, 2), written (moments path) or accumulated (zero-initialised) */
+  int32_t boundary_stride;         /* 0: grad_points7 (n, 7) and grad_colours (n, f) are two dense arrays.  > 0: both are
+                                      columns of ONE row-major array with this many floats per row (the return buffer of a
+                                      multi-GPU rank step: grad_colours = grad_points7 + 7, stride 7 + f) — float32 frames,
+                                      MS_BACKWARD_RASTER on the moments path (stores) and MS_BACKWARD_GAUSSIANS (reads) only */
+  int32_t reserved;
 } ms_frame_grads;
 
 int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
@@ -396,6 +401,10 @@ int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, flo
                     float* out_depths, int64_t* out_ids, void* stream);
 int ms_strip_return_grads(const float* back_rows, const int64_t* send_index, const int32_t* route,
                           int f, int64_t s, float* grad_points7, float* grad_features, void* stream);
+/* the same into ONE zero-initialised (V, 7 + f) array of rows [d packed 2D | d colour] (one line per splat instead of
+ * two; ms_frame_grads.boundary_stride = 7 + f hands it to the per-gaussian pass) */
+int ms_strip_return_rows(const float* back_rows, const int64_t* send_index, const int32_t* route,
+                         int f, int64_t s, float* grad_rows, void* stream);
 
 #ifdef __cplusplus
 }

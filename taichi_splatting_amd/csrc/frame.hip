@@ -317,6 +317,10 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   const bool given = gr->stage == MS_BACKWARD_GAUSSIANS;
   const bool raster_only = gr->stage == MS_BACKWARD_RASTER || d.projected_input;
   const bool moments = !given && frame_uses_moments(desc, gr->deterministic);
+  if (gr->boundary_stride != 0) {
+    MS_CHECK_ARG(gr->boundary_stride >= 7 + d.f && d.dtype == MS_F32, "boundary_stride: rows of >= 7 + f floats, float32 frames");
+    MS_CHECK_ARG(given || (moments && raster_only), "boundary_stride: MS_BACKWARD_GAUSSIANS, or MS_BACKWARD_RASTER on the moments path");
+  }
   if (given) {
     MS_CHECK_ARG(!d.projected_input, "projected input has no per-gaussian backward");
     MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
@@ -327,7 +331,8 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     if (raster_only)
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,
-                                            d.raster.compute_point_heuristic ? (float*)gr->point_heuristic : nullptr, s);
+                                            d.raster.compute_point_heuristic ? (float*)gr->point_heuristic : nullptr, s,
+                                            gr->boundary_stride);
   } else {
     MS_CHECK_ARG(gr->grad_points7 || gr->grad_colours, "no gradient accumulator");
     MS_TRY(ms_raster_bwd(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, d.f, &d.raster,
@@ -350,6 +355,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     a.point_heuristic = d.raster.compute_point_heuristic ? gr->point_heuristic : nullptr;
   } else {
     a.grad_points7 = gr->grad_points7; a.grad_colours = gr->grad_colours;
+    a.boundary_stride = gr->boundary_stride;
   }
   a.extra_points7 = gr->extra_points7; a.extra_depth = gr->extra_depth; a.extra_colours = gr->extra_colours;
   a.sh_degree = d.sh_degree; a.f = d.f;

@@ -78,9 +78,10 @@ int sh_fwd_inplace_launch(const void* params, const void* positions, const void*
 
 // ---- raster_bwd_scan.hip ----------------------------------------------------------------------------------------
 // ms_raster_moments_finalize that also clears the rows it reads (persistent moments buffer)
+// row_stride > 0: grad_points7 / grad_features are columns of one row-major array with that many floats per row
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
-                                   hipStream_t s);
+                                   hipStream_t s, int row_stride = 0);
 
 // ---- gaussian_bwd.hip -------------------------------------------------------------------------------------------
 // One pass over the gaussians for the whole per-gaussian backward of a frame: 2D-boundary gradients (from the raster
@@ -98,6 +99,7 @@ struct GaussianBwdArgs {
   const int32_t* fixed_exp;  // deterministic: binary exponents of the fixed-point scales (raster_bwd_scan.hip)
   const void* grad_points7;  // (n, 7) or NULL
   const void* grad_colours;  // (n, f) or NULL
+  int boundary_stride;       // 0: the two arrays above are dense; > 0: floats per row of the array both are columns of
   // gradients arriving at the frame's own per-gaussian outputs (loss terms on gaussians2d / depth / colours)
   const void *extra_points7, *extra_depth, *extra_colours;
   // SH (degree >= 0): d(colour) -> d(sh params) through the clamp mask of the forward colours

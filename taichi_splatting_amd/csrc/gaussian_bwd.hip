@@ -43,6 +43,7 @@ template <typename T> struct GaussBwdDev {
   void* moments;
   const int32_t* fixed_exp;
   const T *grad_points7, *grad_colours;
+  int gp_stride, gc_stride;       // floats per row of grad_points7 / grad_colours (7 / f unless interleaved)
   const T *extra_points7, *extra_depth, *extra_colours;
   int f;
   const T *camera_position, *colours;
@@ -134,10 +135,10 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
       } else {
         if (a.grad_points7) {
 #pragma unroll
-          for (int k = 0; k < 7; ++k) gp[k] = a.grad_points7[i * 7 + k];
+          for (int k = 0; k < 7; ++k) gp[k] = a.grad_points7[i * a.gp_stride + k];
         }
         if (DEG >= 0 && a.grad_colours)
-          _Pragma("unroll") for (int c = 0; c < GB_MAX_F; ++c) if (c < a.f) gf[c] = a.grad_colours[i * a.f + c];
+          _Pragma("unroll") for (int c = 0; c < GB_MAX_F; ++c) if (c < a.f) gf[c] = a.grad_colours[i * a.gc_stride + c];
       }
       if (a.extra_points7) {
 #pragma unroll
@@ -245,6 +246,8 @@ static int launch_typed(const GaussianBwdArgs& g, hipStream_t s) {
   a.depth = (const T*)g.depth;
   a.moments = g.moments; a.fixed_exp = g.fixed_exp;
   a.grad_points7 = (const T*)g.grad_points7; a.grad_colours = (const T*)g.grad_colours;
+  a.gp_stride = g.boundary_stride > 0 ? g.boundary_stride : 7;
+  a.gc_stride = g.boundary_stride > 0 ? g.boundary_stride : g.f;
   a.extra_points7 = (const T*)g.extra_points7; a.extra_depth = (const T*)g.extra_depth; a.extra_colours = (const T*)g.extra_colours;
   a.f = g.f;
   a.camera_position = (const T*)g.camera_position; a.colours = (const T*)g.colours;

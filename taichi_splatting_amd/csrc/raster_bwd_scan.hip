@@ -557,7 +557,8 @@ template <bool HEUR, bool FIXED, bool REZERO = false>
 __global__ void __launch_bounds__(256)
 raster_moments_finalize_kernel(const float* __restrict__ points, float* __restrict__ moments, int64_t n,
                                float* __restrict__ grad_points, float* __restrict__ grad_feats,
-                               float* __restrict__ heuristic, const int32_t* __restrict__ fixed_exp) {
+                               float* __restrict__ heuristic, const int32_t* __restrict__ fixed_exp,
+                               int gp_stride = 7, int gf_stride = 3) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 r0, r1, r2;
@@ -583,7 +584,7 @@ raster_moments_finalize_kernel(const float* __restrict__ points, float* __restri
     // rasterize() caller, padding rows, culled rows of the frame executor) has an all-zero row; its gradient is
     // exactly zero like the atomic path's (0 / 0 or 0 * NaN otherwise)
     const bool dead = !(alpha > 0.0f) || !(sx > 0.0f) || !(sy > 0.0f);
-    float* o = grad_points + i * 7;
+    float* o = grad_points + i * gp_stride;
     if (dead) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) o[k] = 0.0f;
@@ -610,7 +611,8 @@ raster_moments_finalize_kernel(const float* __restrict__ points, float* __restri
     heuristic[i * 2 + 1] = r2.z * IS2;
   }
   if (grad_feats) {
-    grad_feats[i * 3 + 0] = r1.z; grad_feats[i * 3 + 1] = r1.w; grad_feats[i * 3 + 2] = r2.x;
+    float* c = grad_feats + i * gf_stride;
+    c[0] = r1.z; c[1] = r1.w; c[2] = r2.x;
   }
 }
 
@@ -721,11 +723,12 @@ extern "C" int ms_raster_moments_finalize(const void* points7, const float* mome
 namespace ms {
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
-                                   hipStream_t s) {
+                                   hipStream_t s, int row_stride) {
   if (n == 0) return 0;
   const dim3 grid((unsigned)div_up(n, 256));
+  const int gp_stride = row_stride > 0 ? row_stride : 7, gf_stride = row_stride > 0 ? row_stride : 3;
 #define MS_GO(HEUR, FIXED) raster_moments_finalize_kernel<HEUR, FIXED, true><<<grid, 256, 0, s>>>(      \
-      points7, moments, n, grad_points7, grad_features, point_heuristic, fixed_exp)
+      points7, moments, n, grad_points7, grad_features, point_heuristic, fixed_exp, gp_stride, gf_stride)
   if (point_heuristic) { if (deterministic) MS_GO(true, true); else MS_GO(true, false); }
   else { if (deterministic) MS_GO(false, true); else MS_GO(false, false); }
 #undef MS_GO

@@ -195,6 +195,22 @@ return_grads_kernel(const float* __restrict__ back, const int64_t* __restrict__ 
   else atomic_add_noret(dst, v);
 }
 
+// the same into interleaved rows (V, 7 + f): element e of the reverse buffer goes to element k of row send_index[slot]
+__global__ void __launch_bounds__(256)
+return_rows_kernel(const float* __restrict__ back, const int64_t* __restrict__ send_index,
+                   const int32_t* __restrict__ route, int width, int64_t total, float* __restrict__ rows) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int64_t slot = e / width;
+  const int k = (int)(e - slot * width);
+  const int64_t i = send_index[slot];
+  if (i < 0) return;                      // unused slot of a fixed-capacity bucket
+  float* dst = rows + i * width + k;
+  const float v = back[e];
+  if ((route[i] >> 16) == 1) *dst = v;
+  else atomic_add_noret(dst, v);
+}
+
 }  // namespace ms
 
 using namespace ms;
@@ -276,6 +292,18 @@ extern "C" int ms_strip_return_grads(const float* back_rows, const int64_t* send
   const int64_t total = s * (7 + f);
   return_grads_kernel<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(back_rows, send_index, route, f,
                                                                                        total, grad_points7, grad_features);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_strip_return_rows(const float* back_rows, const int64_t* send_index, const int32_t* route,
+                                    int f, int64_t s, float* grad_rows, void* stream) {
+  MS_CHECK_ARG(s >= 0 && f >= 0, "bad sizes");
+  if (s == 0) return 0;
+  MS_CHECK_ARG(back_rows && send_index && route && grad_rows, "null pointer");
+  const int64_t total = s * (7 + f);
+  return_rows_kernel<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(back_rows, send_index, route, 7 + f,
+                                                                                      total, grad_rows);
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -376,33 +376,41 @@ class ShardedStep(_RankStep):
 
     # ---- backward: strip raster -> gradients of the received rows -> home -> per-gaussian pass ---------------------
     moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc_b), 0))
-    gp = torch.empty((m, 7), dtype=dtype, device=device) if moments_path else torch.zeros((m, 7), dtype=dtype, device=device)
-    gc = torch.empty((m, f), dtype=dtype, device=device) if moments_path else torch.zeros((m, f), dtype=dtype, device=device)
     gr = _lib.FrameGradsC()
     row_bytes = self.px_rows[0] * self.image_size[0] * es
     gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
     gr.stage = _lib.BACKWARD_RASTER
+    bw = 7 + f
     if moments_path:
+      # the finalize pass stores [d packed 2D | d colour] straight into the rows of the return buffer
+      back_send = torch.empty((m, bw), dtype=dtype, device=device)
       gr.moments = frame._moments_buffer(device, m, False).data_ptr()
-    gr.grad_points7, gr.grad_colours = gp.data_ptr(), gc.data_ptr()
+      gr.grad_points7, gr.grad_colours = back_send.data_ptr(), back_send.data_ptr() + 7 * es
+      gr.boundary_stride = bw
+    else:
+      gp = torch.zeros((m, 7), dtype=dtype, device=device)
+      gc = torch.zeros((m, f), dtype=dtype, device=device)
+      gr.grad_points7, gr.grad_colours = gp.data_ptr(), gc.data_ptr()
     _lib.check(lib.ms_frame_backward(ctypes.byref(desc_b), ctypes.byref(in_b), keep_b.data_ptr(), keep_k.data_ptr(),
                                      ctypes.byref(gr), stream), "sharded step (raster backward)")
-    back_send = torch.cat([gp, gc], dim=1)
+    if not moments_path:
+      back_send = torch.cat([gp, gc], dim=1)
     timer.mark('raster_bwd')
     back = torch.empty_like(back_send)
     self.exchange(back, back_send)
     timer.mark('exchange_backward')
 
-    home_p = torch.zeros((n, 7), dtype=dtype, device=device)
-    home_c = torch.zeros((n, f), dtype=dtype, device=device)
+    # home: ONE zero-filled (n, 7 + f) array of rows (a splat's copies sum into one line of it)
+    home = torch.zeros((n, bw), dtype=dtype, device=device)
     if n > 0:
-      _lib.check(lib.ms_strip_return_grads(back.data_ptr(), send_index.data_ptr(), route.data_ptr(), f, m, home_p.data_ptr(),
-                                           home_c.data_ptr(), stream), "sharded step (return)")
+      _lib.check(lib.ms_strip_return_rows(back.data_ptr(), send_index.data_ptr(), route.data_ptr(), f, m, home.data_ptr(),
+                                          stream), "sharded step (return)")
     need = [t.requires_grad for t in (*shard.shape_tensors(), shard.feature)]
     grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
     ga = _lib.FrameGradsC()
     ga.stage = _lib.BACKWARD_GAUSSIANS
-    ga.grad_points7, ga.grad_colours = home_p.data_ptr(), home_c.data_ptr()
+    ga.grad_points7, ga.grad_colours = home.data_ptr(), home.data_ptr() + 7 * es
+    ga.boundary_stride = bw
     ga.grad_position, ga.grad_log_scaling, ga.grad_rotation, ga.grad_alpha_logit = (_lib.ptr(t) for t in grads)
     grad_feature = None
     if need[4]:
@@ -410,7 +418,7 @@ class ShardedStep(_RankStep):
         grad_feature = torch.empty_like(feat)
         ga.grad_feature = grad_feature.data_ptr()
       else:
-        grad_feature = home_c
+        grad_feature = home[:, 7:].contiguous()
     _lib.check(lib.ms_frame_backward(ctypes.byref(desc_a), ctypes.byref(in_a), keep_a.data_ptr(), None,
                                      ctypes.byref(ga), stream), "sharded step (gaussian backward)")
     timer.mark('return_gaussian_bwd')
