@@ -196,19 +196,37 @@ return_grads_kernel(const float* __restrict__ back, const int64_t* __restrict__ 
 }
 
 // the same into interleaved rows (V, 7 + f): element e of the reverse buffer goes to element k of row send_index[slot]
+template <int WIDTH>
 __global__ void __launch_bounds__(256)
 return_rows_kernel(const float* __restrict__ back, const int64_t* __restrict__ send_index,
-                   const int32_t* __restrict__ route, int width, int64_t total, float* __restrict__ rows) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int64_t slot = e / width;
-  const int k = (int)(e - slot * width);
+                   const int32_t* __restrict__ route, int64_t slots, float* __restrict__ rows) {
+  // one thread per slot; rows of an even number of floats move as 64-bit words
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= slots) return;
   const int64_t i = send_index[slot];
   if (i < 0) return;                      // unused slot of a fixed-capacity bucket
-  float* dst = rows + i * width + k;
-  const float v = back[e];
-  if ((route[i] >> 16) == 1) *dst = v;
-  else atomic_add_noret(dst, v);
+  const float* src = back + slot * WIDTH;
+  float* dst = rows + i * WIDTH;
+  float v[WIDTH];
+  if (WIDTH % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < WIDTH; k += 2) { const float2 p = *reinterpret_cast<const float2*>(src + k); v[k] = p.x; v[k + 1] = p.y; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < WIDTH; ++k) v[k] = src[k];
+  }
+  if ((route[i] >> 16) == 1) {
+    if (WIDTH % 2 == 0) {
+#pragma unroll
+      for (int k = 0; k < WIDTH; k += 2) *reinterpret_cast<float2*>(dst + k) = make_float2(v[k], v[k + 1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < WIDTH; ++k) dst[k] = v[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < WIDTH; ++k) atomic_add_noret(dst + k, v[k]);
+  }
 }
 
 }  // namespace ms
@@ -301,9 +319,15 @@ extern "C" int ms_strip_return_rows(const float* back_rows, const int64_t* send_
   MS_CHECK_ARG(s >= 0 && f >= 0, "bad sizes");
   if (s == 0) return 0;
   MS_CHECK_ARG(back_rows && send_index && route && grad_rows, "null pointer");
-  const int64_t total = s * (7 + f);
-  return_rows_kernel<<<(unsigned)div_up(total, 256), 256, 0, (hipStream_t)stream>>>(back_rows, send_index, route, 7 + f,
-                                                                                      total, grad_rows);
+  MS_CHECK_ARG(f >= 1 && f <= 4, "ms_strip_return_rows: 1..4 colour channels");
+  const dim3 grid((unsigned)div_up(s, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (f) {
+    case 1: return_rows_kernel<8><<<grid, block, 0, st>>>(back_rows, send_index, route, s, grad_rows); break;
+    case 2: return_rows_kernel<9><<<grid, block, 0, st>>>(back_rows, send_index, route, s, grad_rows); break;
+    case 3: return_rows_kernel<10><<<grid, block, 0, st>>>(back_rows, send_index, route, s, grad_rows); break;
+    default: return_rows_kernel<11><<<grid, block, 0, st>>>(back_rows, send_index, route, s, grad_rows); break;
+  }
   MS_CHECK_LAUNCH();
   return 0;
 }
