@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_VERSION 301  /* 0.3.1: frame executor; row-strided 2D-boundary gradients (ms_frame_grads.boundary_stride, ms_strip_return_rows) */
+#define MS_VERSION 302  /* 0.3.2: frame executor; row-strided / gathered 2D-boundary gradients for the rank steps */
 
 enum { MS_F32 = 0, MS_F64 = 1 };
 
@@ -311,7 +311,14 @@ typedef struct ms_frame_grads {
                                       columns of ONE row-major array with this many floats per row (the return buffer of a
                                       multi-GPU rank step: grad_colours = grad_points7 + 7, stride 7 + f) — float32 frames,
                                       MS_BACKWARD_RASTER on the moments path (stores) and MS_BACKWARD_GAUSSIANS (reads) only */
-  int32_t reserved;
+  int32_t gather_world;            /* MS_BACKWARD_GAUSSIANS, > 0: the 2D-boundary gradient of gaussian i is the SUM of the rows
+                                      gather_slots[i * gather_world + c], c < (gather_route[i] >> 16), of gather_rows
+                                      (rows of boundary_stride floats: [d packed 2D | d colour]; slot < 0: no row) — the
+                                      receive buffer of a rank step's reverse exchange read in place: no return pass, no
+                                      home array.  grad_points7 / grad_colours are then unused */
+  const void* gather_rows;
+  const int32_t* gather_slots;     /* out_slots of ms_strip_route_pack_slots */
+  const int32_t* gather_route;     /* out_route of ms_strip_route_count */
 } ms_frame_grads;
 
 int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
@@ -397,6 +404,13 @@ int ms_strip_route_pack(const float* points7, const float* features, const float
                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
                         int64_t bucket_capacity, int32_t* overflow_flag,
                         float* out_rows, int64_t* out_send_index, void* stream);
+/* the same, and out_slots[i * world + c] (int32, may be NULL) = row of out_rows that holds copy c of local splat i
+ * (c < copies of out_route), -1 for a copy dropped by a full bucket: what ms_frame_grads.gather_slots reads */
+int ms_strip_route_pack_slots(const float* points7, const float* features, const float* depths,
+                              const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                              const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                              int64_t bucket_capacity, int32_t* overflow_flag,
+                              float* out_rows, int64_t* out_send_index, int32_t* out_slots, void* stream);
 int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, float* out_features,
                     float* out_depths, int64_t* out_ids, void* stream);
 int ms_strip_return_grads(const float* back_rows, const int64_t* send_index, const int32_t* route,

@@ -81,7 +81,8 @@ class FrameGradsC(ctypes.Structure):
     ('grad_position', c_void_p), ('grad_log_scaling', c_void_p), ('grad_rotation', c_void_p),
     ('grad_alpha_logit', c_void_p), ('grad_feature', c_void_p), ('grad_camera', c_void_p),
     ('point_heuristic', c_void_p),
-    ('boundary_stride', c_int32), ('reserved', c_int32),
+    ('boundary_stride', c_int32), ('gather_world', c_int32),
+    ('gather_rows', c_void_p), ('gather_slots', c_void_p), ('gather_route', c_void_p),
   ]
 
 
@@ -110,6 +111,7 @@ SIGNATURES = {
   'ms_strip_route_pack': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 3 + [c_int64, c_void_p] + [c_void_p] * 2 + [c_void_p]),
   'ms_strip_unpack': (c_int, [c_void_p, c_int64, c_int] + [c_void_p] * 4 + [c_void_p]),
   'ms_strip_return_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+  'ms_strip_route_pack_slots': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 3 + [c_int64] + [c_void_p] * 5),
   'ms_strip_return_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
   'ms_fractional_update': (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),

@@ -323,7 +323,11 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   }
   if (given) {
     MS_CHECK_ARG(!d.projected_input, "projected input has no per-gaussian backward");
-    MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
+    if (gr->gather_world > 0)
+      MS_CHECK_ARG(gr->gather_rows && gr->gather_slots && gr->gather_route && gr->boundary_stride >= 7 + d.f && d.dtype == MS_F32,
+                   "gathered boundary gradients: rows, slots, route, boundary_stride >= 7 + f, float32");
+    else
+      MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
   } else if (moments) {
     MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
     MS_TRY(ms_raster_bwd_moments(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
@@ -356,6 +360,10 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   } else {
     a.grad_points7 = gr->grad_points7; a.grad_colours = gr->grad_colours;
     a.boundary_stride = gr->boundary_stride;
+    if (given && gr->gather_world > 0) {
+      a.gather_world = gr->gather_world; a.gather_rows = gr->gather_rows;
+      a.gather_slots = gr->gather_slots; a.gather_route = gr->gather_route;
+    }
   }
   a.extra_points7 = gr->extra_points7; a.extra_depth = gr->extra_depth; a.extra_colours = gr->extra_colours;
   a.sh_degree = d.sh_degree; a.f = d.f;

@@ -100,6 +100,11 @@ struct GaussianBwdArgs {
   const void* grad_points7;  // (n, 7) or NULL
   const void* grad_colours;  // (n, f) or NULL
   int boundary_stride;       // 0: the two arrays above are dense; > 0: floats per row of the array both are columns of
+  // gather_world > 0: d(packed 2D gaussian), d(colour) of gaussian i = sum of rows gather_slots[i * gather_world + c],
+  // c < gather_route[i] >> 16, of gather_rows (boundary_stride floats per row)
+  int gather_world;
+  const void* gather_rows;
+  const int32_t *gather_slots, *gather_route;
   // gradients arriving at the frame's own per-gaussian outputs (loss terms on gaussians2d / depth / colours)
   const void *extra_points7, *extra_depth, *extra_colours;
   // SH (degree >= 0): d(colour) -> d(sh params) through the clamp mask of the forward colours

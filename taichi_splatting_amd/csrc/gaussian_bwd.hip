@@ -44,6 +44,9 @@ template <typename T> struct GaussBwdDev {
   const int32_t* fixed_exp;
   const T *grad_points7, *grad_colours;
   int gp_stride, gc_stride;       // floats per row of grad_points7 / grad_colours (7 / f unless interleaved)
+  int gather_world;               // > 0: rows gathered from the reverse exchange's receive buffer (frame_internal.h)
+  const T* gather_rows;
+  const int32_t *gather_slots, *gather_route;
   const T *extra_points7, *extra_depth, *extra_colours;
   int f;
   const T *camera_position, *colours;
@@ -132,6 +135,18 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         gf[0] = (T)r1.z; gf[1] = (T)r1.w; gf[2] = (T)r2.x;
         heur0 = (T)(alpha * alpha * r2.y);          // backward.py:190-194
         heur1 = (T)(r2.z * IS2);
+      } else if (a.gather_world > 0) {
+        // the copies of this splat came back in the rows the pack kernel sent them out in: summed in copy order
+        const int copies = a.gather_route[i] >> 16;
+        for (int c = 0; c < copies; ++c) {
+          const int slot = a.gather_slots[i * a.gather_world + c];
+          if (slot < 0) continue;
+          const T* row = a.gather_rows + (int64_t)slot * a.gp_stride;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) gp[k] += row[k];
+          if (DEG >= 0)
+            _Pragma("unroll") for (int ch = 0; ch < GB_MAX_F; ++ch) if (ch < a.f) gf[ch] += row[7 + ch];
+        }
       } else {
         if (a.grad_points7) {
 #pragma unroll
@@ -246,6 +261,8 @@ static int launch_typed(const GaussianBwdArgs& g, hipStream_t s) {
   a.depth = (const T*)g.depth;
   a.moments = g.moments; a.fixed_exp = g.fixed_exp;
   a.grad_points7 = (const T*)g.grad_points7; a.grad_colours = (const T*)g.grad_colours;
+  a.gather_world = g.gather_world; a.gather_rows = (const T*)g.gather_rows;
+  a.gather_slots = g.gather_slots; a.gather_route = g.gather_route;
   a.gp_stride = g.boundary_stride > 0 ? g.boundary_stride : 7;
   a.gc_stride = g.boundary_stride > 0 ? g.boundary_stride : g.f;
   a.extra_points7 = (const T*)g.extra_points7; a.extra_depth = (const T*)g.extra_depth; a.extra_colours = (const T*)g.extra_colours;

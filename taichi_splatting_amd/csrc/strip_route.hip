@@ -107,7 +107,7 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
                   const int64_t* __restrict__ ids, int f, int v, int world, int nblocks, int64_t index_offset,
                   const int32_t* __restrict__ route, const int32_t* __restrict__ block_offsets,
                   const int64_t* __restrict__ send_counts, int64_t bucket_capacity, int32_t* __restrict__ overflow,
-                  float* __restrict__ rows, int64_t* __restrict__ send_index) {
+                  float* __restrict__ rows, int64_t* __restrict__ send_index, int32_t* __restrict__ slots) {
   constexpr int WAVES = ROUTE_BLOCK / 64;
   __shared__ int s_wave_count[WAVES][ROUTE_MAX_WORLD];
   __shared__ int64_t s_bucket_start[ROUTE_MAX_WORLD];
@@ -149,8 +149,12 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
     int before = 0;
     for (int w = 0; w < wave; ++w) before += s_wave_count[w][d];
     const int64_t in_bucket = (int64_t)block_offsets[(int64_t)d * nblocks + blockIdx.x] + before + __popcll(m & lt_mask);
-    if (bucket_capacity > 0 && in_bucket >= bucket_capacity) continue;
+    if (bucket_capacity > 0 && in_bucket >= bucket_capacity) {
+      if (slots) slots[(int64_t)i * world + (d - first)] = -1;        // dropped copy (overflow is flagged)
+      continue;
+    }
     const int64_t slot = s_bucket_start[d] + in_bucket;
+    if (slots) slots[(int64_t)i * world + (d - first)] = (int32_t)slot;
     float* row = rows + slot * width;
 #pragma unroll
     for (int k = 0; k < 7; ++k) row[k] = g[k];
@@ -273,11 +277,11 @@ extern "C" int ms_strip_route_count(const float* points7, const float* depth, in
   return 0;
 }
 
-extern "C" int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
-                                   const int64_t* ids, int f, int v, int world, int64_t index_offset,
-                                   const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
-                                   int64_t bucket_capacity, int32_t* overflow_flag,
-                                   float* out_rows, int64_t* out_send_index, void* stream) {
+extern "C" int ms_strip_route_pack_slots(const float* points7, const float* features, const float* depths,
+                                         const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                                         int64_t bucket_capacity, int32_t* overflow_flag,
+                                         float* out_rows, int64_t* out_send_index, int32_t* out_slots, void* stream) {
   MS_CHECK_ARG(v >= 0 && f >= 0 && world >= 1 && world <= ROUTE_MAX_WORLD, "bad sizes");
   if (v == 0) return 0;
   MS_CHECK_ARG(points7 && depths && route && block_offsets && send_counts && (f == 0 || features), "null pointer");
@@ -286,9 +290,18 @@ extern "C" int ms_strip_route_pack(const float* points7, const float* features, 
   route_pack_kernel<<<nblocks, ROUTE_BLOCK, 0, (hipStream_t)stream>>>(points7, features, depths, ids, f, v, world,
                                                                        nblocks, index_offset, route, block_offsets,
                                                                        send_counts, bucket_capacity, overflow_flag,
-                                                                       out_rows, out_send_index);
+                                                                       out_rows, out_send_index, out_slots);
   MS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
+                                   const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                                   const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                                   int64_t bucket_capacity, int32_t* overflow_flag,
+                                   float* out_rows, int64_t* out_send_index, void* stream) {
+  return ms_strip_route_pack_slots(points7, features, depths, ids, f, v, world, index_offset, route, block_offsets,
+                                   send_counts, bucket_capacity, overflow_flag, out_rows, out_send_index, nullptr, stream);
 }
 
 extern "C" int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, float* out_features,

@@ -343,11 +343,13 @@ class ShardedStep(_RankStep):
     send_index = torch.full((m,), -1, dtype=torch.int64, device=device)
     if self.flags is None:
       self.flags = torch.zeros((2,), dtype=torch.int32, device=device)
+    # slots[i, c] = row of the send buffer that carries copy c of gaussian i: where its gradient comes back
+    slots = torch.empty((max(n, 1), world), dtype=torch.int32, device=device)
     if n > 0:
-      _lib.check(lib.ms_strip_route_pack(points7.data_ptr(), colours.data_ptr(), depth.data_ptr(), None, f, n, world,
-                                         self.index_offset, route.data_ptr(), block_offsets.data_ptr(),
-                                         send_counts.data_ptr(), cap, self.flags.data_ptr(), send.data_ptr(),
-                                         send_index.data_ptr(), stream), "sharded step (pack)")
+      _lib.check(lib.ms_strip_route_pack_slots(points7.data_ptr(), colours.data_ptr(), depth.data_ptr(), None, f, n, world,
+                                               self.index_offset, route.data_ptr(), block_offsets.data_ptr(),
+                                               send_counts.data_ptr(), cap, self.flags.data_ptr(), send.data_ptr(),
+                                               send_index.data_ptr(), slots.data_ptr(), stream), "sharded step (pack)")
     timer.mark('route_pack')
     recv = torch.empty_like(send)
     self.exchange(recv, send)
@@ -400,16 +402,23 @@ class ShardedStep(_RankStep):
     self.exchange(back, back_send)
     timer.mark('exchange_backward')
 
-    # home: ONE zero-filled (n, 7 + f) array of rows (a splat's copies sum into one line of it)
-    home = torch.zeros((n, bw), dtype=dtype, device=device)
-    if n > 0:
-      _lib.check(lib.ms_strip_return_rows(back.data_ptr(), send_index.data_ptr(), route.data_ptr(), f, m, home.data_ptr(),
-                                          stream), "sharded step (return)")
     need = [t.requires_grad for t in (*shard.shape_tensors(), shard.feature)]
     grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
     ga = _lib.FrameGradsC()
     ga.stage = _lib.BACKWARD_GAUSSIANS
-    ga.grad_points7, ga.grad_colours = home.data_ptr(), home.data_ptr() + 7 * es
+    home = None
+    if degree >= 0 or not need[4]:
+      # the per-gaussian pass reads every splat's returned rows straight from the receive buffer (summed in copy
+      # order): no return pass, no home array, no fill
+      ga.gather_world, ga.gather_rows = world, back.data_ptr()
+      ga.gather_slots, ga.gather_route = slots.data_ptr(), route.data_ptr()
+    else:
+      # plain colours with a feature gradient wanted: the caller needs d(colour) as an array — rows summed at home
+      home = torch.zeros((n, bw), dtype=dtype, device=device)
+      if n > 0:
+        _lib.check(lib.ms_strip_return_rows(back.data_ptr(), send_index.data_ptr(), route.data_ptr(), f, m, home.data_ptr(),
+                                            stream), "sharded step (return)")
+      ga.grad_points7, ga.grad_colours = home.data_ptr(), home.data_ptr() + 7 * es
     ga.boundary_stride = bw
     ga.grad_position, ga.grad_log_scaling, ga.grad_rotation, ga.grad_alpha_logit = (_lib.ptr(t) for t in grads)
     grad_feature = None
