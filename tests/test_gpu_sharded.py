@@ -127,6 +127,85 @@ def test_routing_kernels_match_torch_formulation(world, bounds):
       assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), k
 
 
+@pytest.mark.parametrize('world,capacity_frac', [(1, None), (3, None), (8, None), (8, 0.6)])
+def test_return_rows_and_slot_table_match_return_grads(world, capacity_frac):
+  """ms_strip_route_pack_slots / ms_strip_return_rows (interleaved home rows) / the slot-table gather against
+  ms_strip_route_pack + ms_strip_return_grads: same send buffer, same per-splat gradient sums; with buckets too small
+  for the splats (capacity_frac) the dropped copies carry slot -1 and contribute nothing anywhere"""
+  import ctypes
+  from taichi_splatting_amd import RasterConfig, _lib
+  from taichi_splatting_amd import distributed as D
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  lib = _lib.load()
+  torch.manual_seed(world)
+  size, n, f = (256, 512), 30000, 3
+  g = random_2d_gaussians(n, size, scale_factor=3.0, alpha_range=(0.05, 0.9)).to(DEV)
+  p = project_gaussians2d(g).contiguous()
+  feats, depth = g.feature.contiguous(), g.depths.reshape(-1).contiguous()
+  cfg = RasterConfig()
+  bounds = D.strip_bounds((size[1] + 15) // 16, world)
+  stream = _lib.current_stream(p.device)
+  nb = lib.ms_strip_route_blocks(n)
+  route = torch.empty((n,), dtype=torch.int32, device=DEV)
+  block_offsets = torch.empty((world * nb,), dtype=torch.int32, device=DEV)
+  send_counts = torch.empty((world,), dtype=torch.int64, device=DEV)
+  bounds_c = (ctypes.c_int32 * (world + 1))(*bounds)
+  _lib.check(lib.ms_strip_route_count(p.data_ptr(), depth.data_ptr(), n, size[1], cfg.tile_size, cfg.alpha_threshold,
+                                      ctypes.cast(bounds_c, ctypes.c_void_p), world, route.data_ptr(),
+                                      block_offsets.data_ptr(), send_counts.data_ptr(), stream), 'count')
+  biggest = int(send_counts.max())
+  cap = biggest if capacity_frac is None else max(int(biggest * capacity_frac), 1)
+  m, width = world * cap, 9 + f
+  flag = torch.zeros((2,), dtype=torch.int32, device=DEV)
+
+  def pack(with_slots):
+    send = torch.zeros((m, width), device=DEV)
+    send_index = torch.full((m,), -1, dtype=torch.int64, device=DEV)
+    slots = torch.full((n, world), -7, dtype=torch.int32, device=DEV)
+    if with_slots:
+      _lib.check(lib.ms_strip_route_pack_slots(p.data_ptr(), feats.data_ptr(), depth.data_ptr(), None, f, n, world, 0,
+                                               route.data_ptr(), block_offsets.data_ptr(), send_counts.data_ptr(), cap,
+                                               flag.data_ptr(), send.data_ptr(), send_index.data_ptr(), slots.data_ptr(),
+                                               stream), 'pack_slots')
+    else:
+      _lib.check(lib.ms_strip_route_pack(p.data_ptr(), feats.data_ptr(), depth.data_ptr(), None, f, n, world, 0,
+                                         route.data_ptr(), block_offsets.data_ptr(), send_counts.data_ptr(), cap,
+                                         flag.data_ptr(), send.data_ptr(), send_index.data_ptr(), stream), 'pack')
+    return send, send_index, slots
+
+  send_a, index_a, _ = pack(False)
+  send_b, index_b, slots = pack(True)
+  assert torch.equal(send_a, send_b) and torch.equal(index_a, index_b)
+  assert bool(flag[0]) == (capacity_frac is not None)
+
+  # the slot table: copy c of splat i sits in row slots[i, c] of the send buffer (or was dropped)
+  copies = (route >> 16).long()
+  for c in range(int(copies.max())):
+    has = copies > c
+    sl = slots[has, c].long()
+    kept = sl >= 0
+    assert torch.equal(index_b[sl[kept]], torch.nonzero(has).reshape(-1)[kept])
+  assert int((slots[:, 0][copies > 0] >= 0).sum()) + int((slots[:, 1:] >= 0).sum() if world > 1 else 0) == int((index_b >= 0).sum())
+
+  back = torch.randn((m, 7 + f), device=DEV)
+  gp, gf = torch.zeros((n, 7), device=DEV), torch.zeros((n, f), device=DEV)
+  _lib.check(lib.ms_strip_return_grads(back.data_ptr(), index_b.data_ptr(), route.data_ptr(), f, m, gp.data_ptr(),
+                                       gf.data_ptr(), stream), 'return_grads')
+  home = torch.zeros((n, 7 + f), device=DEV)
+  _lib.check(lib.ms_strip_return_rows(back.data_ptr(), index_b.data_ptr(), route.data_ptr(), f, m, home.data_ptr(), stream),
+             'return_rows')
+  want = torch.cat([gp, gf], dim=1)
+  assert torch.allclose(home, want, rtol=1e-5, atol=1e-5)
+  # the gather the per-gaussian pass does (gaussian_bwd.hip, gather_world > 0), restated in torch
+  gathered = torch.zeros((n, 7 + f), device=DEV)
+  for c in range(world):
+    sl = slots[:, c].long()
+    use = (copies > c) & (sl >= 0)
+    gathered[use] += back[sl[use]]
+  assert torch.allclose(gathered, want, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('world,dtype_name,balance', [(2, 'float64', False), (3, 'float64', True), (4, 'float32', False),
                                                       (3, 'float32', True), (8, 'float32', False)])
 def test_sharded_step_matches_full_frame(world, dtype_name, balance):
