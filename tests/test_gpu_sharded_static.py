@@ -156,6 +156,28 @@ def test_world_of_one_equals_render_gaussians_and_flags_bucket_overflow():
   assert st['overlap_overflow'] and st['overlaps'] > 4096 and float(image.abs().max()) == 0.0
 
 
+def test_world_of_one_with_plain_colours():
+  """use_sh=False: d(colour) IS the feature gradient, so ShardedStep sums the returned rows into an interleaved home
+  array (ms_strip_return_rows) instead of letting the per-gaussian pass gather them"""
+  from taichi_splatting_amd import RasterConfig, render_gaussians, sharded
+  size = (256, 160)
+  g, cam, G = _scene(2, n=12000, size=size)
+  g = g.replace(feature=torch.rand(g.position.shape[0], 3))
+  cfg = RasterConfig()
+  loss_fn = lambda img, px: (img * G[px[0]:px[1]]).sum()
+  full = g.to(DEV).requires_grad_(True)
+  r = render_gaussians(full, cam, cfg, use_sh=False)
+  (r.image * G).sum().backward()
+  for cls in (sharded.ShardedStep, sharded.StripStep):
+    mine = g.to(DEV).requires_grad_(True)
+    step = cls(size, cfg, cam.depth_range, 0, 1, [0, 10])
+    step.probe(mine, cam, False)
+    image, _ = step.step(mine, cam, loss_fn, use_sh=False)
+    assert torch.equal(image, r.image.detach())
+    good, worst = _close(_grads(mine), _grads(full))
+    assert good, (cls.__name__, worst)
+
+
 def test_sharded_step_in_a_hip_graph():
   from taichi_splatting_amd import RasterConfig, frame, sharded
   size = (256, 160)
