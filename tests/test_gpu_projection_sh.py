@@ -192,6 +192,28 @@ def test_sh_random_f32_vs_oracle(seed):
     assert torch.allclose(g_h.cpu(), g_o, atol=1e-5), (g_h.cpu() - g_o).abs().max()
 
 
+@pytest.mark.parametrize('seed,n', [(0, 1), (1, 77), (2, 4096 + 5), (3, 30000)])
+def test_frame_sh_degree3_colours_vs_oracle(seed, n):
+  """The frame executor's float32 RGB degree-3 SH kernel (sh_fwd_rows_deg3_kernel: coalesced block loads, 4 x 4
+  summation) against the oracle in float64 on the visible set, at the reference's tolerance (atol 1e-5,
+  tests/util.py:62-63) — not only against the modular kernel"""
+  from taichi_splatting_amd import RasterConfig, render_gaussians
+  from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+  torch.manual_seed(seed)
+  cam = random_camera(image_size=(192, 128))
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9), margin=0.5)
+  g = g.replace(feature=(torch.rand(n, 3, 16) - 0.5) * 0.8)
+  r = render_gaussians(g.to(DEV), cam.to(device=DEV), RasterConfig(), use_sh=True)
+  idx = r.points.idx.cpu()
+  if idx.numel() == 0:
+    return
+  cam_pos = torch.inverse(cam.T_camera_world.double())[:3, 3]
+  want = osh.evaluate_sh_at(g.feature.double(), g.position.double(), idx, cam_pos)
+  got = r.points.features.detach().cpu().double()
+  assert got.shape == want.shape
+  assert float((got - want).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_camera_position_kernel_matches_torch_inverse(dtype):
   # perspective/params.py:62-65: inverse(T_camera_world)[0:3, 3]
