@@ -17,11 +17,14 @@ them visible in results:
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import ctypes
 import gc
 from dataclasses import dataclass, replace
 import os
+import threading
+import time
 from typing import Optional, Tuple
 import weakref
 
@@ -38,9 +41,15 @@ K_SLACK = 1.25            # capacity = K_SLACK x the largest overlap total seen 
 K_GRANULE = 1 << 16
 
 _k_capacity = {}          # scene-shape key -> overlap-list capacity
-_k_host = {}              # device index -> (pinned int32[1], torch.cuda.Event)
-_moments = {}             # (device index, n, deterministic) -> persistent accumulator rows, zero between frames
+_k_host = {}              # device index -> KSlots: a ring of pinned int32 words, ONE PER FRAME IN FLIGHT
+_moments = collections.OrderedDict()   # (device index, stream, n, deterministic) -> accumulator rows, zero between frames
+_moments_pinned = set()   # keys whose buffer address is baked into a captured HIP graph: never evicted
 _identity = {}            # (device index, n) -> arange(n) int64
+_lock = threading.RLock() # guards the caches above and serialises the enqueue of a backward pass (ctypes drops the GIL)
+
+MOMENTS_LRU = 4           # accumulator buffers kept per device (scene sizes / streams alternating in one process)
+K_SLOTS = 64              # pinned K words per device; a frame holds one from its forward until it has looked at K
+STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
 host_syncs = 0            # forward-pass waits on the overlap total (non-stalling: the frame is already enqueued)
 point_syncs = 0           # LazyPoints materialisations (host read of the visible count)
@@ -86,25 +95,59 @@ def _round_capacity(k: int) -> int:
 K_PENDING = -(1 << 31)      # sentinel the host writes into the pinned word before a frame; K itself is >= 0
 
 
+class KSlots:
+  """Pinned int32 words the frames' K kernels write (``ms_frame_project_count(k_host)``), one per frame in flight.
+
+  Round 3 kept ONE word per device: a second frame enqueued before the first had looked at its overlap total (a
+  viewer thread next to a training thread, two frames rendered back to back before either is settled) reset the
+  word and the first frame then validated its capacity against the other frame's K."""
+
+  def __init__(self):
+    self.words = torch.zeros((K_SLOTS,), dtype=torch.int32).pin_memory()
+    self.view = self.words.numpy()
+    self.busy = [False] * K_SLOTS
+    self.next = 0
+
+  def acquire(self):
+    """(slot index or -1, one-element pinned tensor, its numpy view)"""
+    with _lock:
+      for _ in range(K_SLOTS):
+        i = self.next
+        self.next = (i + 1) % K_SLOTS
+        if not self.busy[i]:
+          self.busy[i] = True
+          return i, self.words[i:i + 1], self.view[i:i + 1]
+    word = torch.zeros((1,), dtype=torch.int32).pin_memory()       # more than K_SLOTS unsettled frames: a private word
+    return -1, word, word.numpy()
+
+  def release(self, i):
+    if i >= 0:
+      self.busy[i] = False
+
+
 def _pinned_k(device):
-  """(pinned int32 word the frame's K kernel writes, its numpy view for polling, an event as the fallback wait)"""
-  entry = _k_host.get(device.index)
-  if entry is None:
-    word = torch.zeros((1,), dtype=torch.int32).pin_memory()
-    entry = _k_host[device.index] = (word, word.numpy(), torch.cuda.Event())
-  return entry
+  """A pinned int32 word of its own for the frame about to be enqueued: (slot, tensor, numpy view, event, ring)"""
+  with _lock:
+    ring = _k_host.get(device.index)
+    if ring is None:
+      ring = _k_host[device.index] = KSlots()
+  slot, word, view = ring.acquire()
+  return slot, word, view, torch.cuda.Event(), ring
 
 
 def _wait_for_k(k_np, k_event) -> int:
   """The host's one wait per eager frame.  Polling the pinned word the K kernel writes returns within microseconds of
   the write; ``Event.synchronize`` (an interrupt-driven sleep) cost 0.3-0.5 ms of wake-up latency per frame, which
   at 1 M gaussians left the GPU idle for a third of the frame."""
-  import time
   deadline = time.perf_counter() + 2.0
+  spins = 0
   while k_np[0] == K_PENDING:
-    if time.perf_counter() > deadline:      # never seen; a lost write must not hang the caller
-      k_event.synchronize()
-      break
+    spins += 1
+    if spins & 63 == 0:
+      time.sleep(0)                         # let other Python threads run: the poll holds the GIL otherwise
+      if time.perf_counter() > deadline:    # never seen; a lost write must not hang the caller
+        k_event.synchronize()
+        break
   return int(k_np[0])
 
 
@@ -130,13 +173,21 @@ def parked_gc():
       gc.enable()
 
 
-def release_caches():
+def release_caches(force: bool = False):
   """Drop what the executor keeps between frames: the persistent moments accumulators (64 B per gaussian), the shared
-  identity index lists, the remembered overlap capacities and the pinned K words."""
-  _moments.clear()
-  _identity.clear()
-  _k_capacity.clear()
-  _k_host.clear()
+  identity index lists, the remembered overlap capacities and the pinned K words.  Accumulators whose address a
+  captured HIP graph replays into (``FrameGraph`` / ``torch.cuda.graph``) are kept unless ``force`` — freeing them
+  would let the next replay accumulate into memory the allocator has handed to someone else; pass ``force=True`` only
+  after every such graph is gone."""
+  with _lock:
+    for key in list(_moments):
+      if force or key not in _moments_pinned:
+        del _moments[key]
+    if force:
+      _moments_pinned.clear()
+    _identity.clear()
+    _k_capacity.clear()
+    _k_host.clear()
 
 
 def identity_indexes(n: int, device) -> torch.Tensor:
@@ -153,15 +204,35 @@ def identity_indexes(n: int, device) -> torch.Tensor:
 
 def _moments_buffer(device, n: int, deterministic: bool) -> torch.Tensor:
   """Persistent (n, MOMENT_ROW) accumulator of the raster backward: zero on entry of every backward pass, and zero
-  again when it returns (the per-gaussian pass clears the rows it reads) — no 64 B-per-gaussian fill per frame."""
-  key = (device.index, int(n), bool(deterministic))
-  buf = _moments.get(key)
-  if buf is None:
-    for k in [k for k in _moments if k[0] == device.index and k[2] == bool(deterministic)]:
-      del _moments[k]                       # one scene size at a time per device
-    buf = _moments[key] = torch.zeros((max(n, 1), _lib.MOMENT_ROW), dtype=torch.int64 if deterministic else torch.float32,
-                                      device=device)
+  again when it returns (the per-gaussian pass clears the rows it reads) — no 64 B-per-gaussian fill per frame.
+
+  One buffer per (device, stream, size, mode): two backward passes on DIFFERENT streams never share rows (on one
+  stream they run one after the other and the rows are zero in between).  A small LRU per device instead of "one
+  size at a time": alternating two scene sizes (a 3D model and ``rasterize()`` of a 2D set) no longer reallocates and
+  zero-fills on every backward.  A buffer handed out during HIP-graph capture is pinned: its address is part of the
+  graph."""
+  stream = int(torch.cuda.current_stream(device).cuda_stream)
+  key = (device.index, stream, int(n), bool(deterministic))
+  with _lock:
+    buf = _moments.get(key)
+    if buf is None:
+      mine = [k for k in _moments if k[0] == device.index and k not in _moments_pinned]
+      for k in mine[:max(0, len(mine) - (MOMENTS_LRU - 1))]:
+        del _moments[k]                     # least recently used first (OrderedDict order)
+      buf = _moments[key] = torch.zeros((max(n, 1), _lib.MOMENT_ROW),
+                                        dtype=torch.int64 if deterministic else torch.float32, device=device)
+    else:
+      _moments.move_to_end(key)
+    if torch.cuda.is_current_stream_capturing():
+      _moments_pinned.add(key)
   return buf
+
+
+def _drop_moments():
+  """After a failed backward enqueue the accumulator rows may be half-written: start from fresh buffers."""
+  with _lock:
+    _moments.clear()
+    _moments_pinned.clear()
 
 
 class FrameState:
@@ -178,6 +249,9 @@ class FrameState:
     self.children = []            # (weakref to a tensor handed out, index list or None, 'points7' | 'colours')
     self.y0 = 0
     self.pending = None           # eager mode: the wait for K + capacity check, run once by the frame's caller
+    self.captured = False         # enqueued under HIP-graph capture: k_word / k_view = the pinned word replays write K to
+    self.k_word = self.k_view = None
+    self.overflowed = 0           # largest overlap total a replay was seen to exceed the capacity with (sticky)
 
   def settle(self):
     if self.pending is not None:
@@ -235,11 +309,24 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")
-  k_word, k_np, k_event = (None, None, None) if capturing else _pinned_k(device)
-  if not capturing:
+  if capturing:
+    # a pinned word of the captured frame's own: every replay writes its overlap total there, so the host can tell
+    # an overflowed replay (background-only image, zero gradients) WITHOUT touching the device — see check_replays()
+    slot, ring, k_event = -1, None, None
+    k_word = torch.full((1,), 0, dtype=torch.int32).pin_memory()
+    k_np = k_word.numpy()
+    state.k_word, state.k_view, state.captured = k_word, k_np, True
+    _captured_frames.append(weakref.ref(state))
+  else:
+    slot, k_word, k_np, k_event, ring = _pinned_k(device)
     k_np[0] = K_PENDING
-  _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
-                                        None if capturing else k_word.data_ptr(), None, stream), what)
+  try:
+    _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
+                                          k_word.data_ptr(), None, stream), what)
+  except Exception:
+    if ring is not None:
+      ring.release(slot)
+    raise
   if not capturing:
     k_event.record(torch.cuda.current_stream(device))
 
@@ -262,7 +349,10 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   def settle():
     global host_syncs
     state.pending = None
-    k_total = _wait_for_k(k_np, k_event)
+    try:
+      k_total = _wait_for_k(k_np, k_event)
+    finally:
+      ring.release(slot)        # this frame's word may serve another frame from here on
     host_syncs += 1
     if k_total < 0:
       raise OverflowError(f"{what}: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
@@ -272,7 +362,8 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
         visibility.zero_()
       map_raster(_round_capacity(k_total * K_SLACK))
     state.k = k_total
-    _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+    with _lock:
+      _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
 
   state.capacity = 0
   if capacity > 0:
@@ -281,6 +372,47 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     settle()
   else:
     state.pending = settle
+
+
+_captured_frames = []      # weak references to the FrameStates of frames captured into HIP graphs
+
+
+class FrameOverflow(OverflowError):
+  """A frame replayed from a HIP graph found more tile overlaps than its captured buffers hold: that replay's image is
+  the background only and its gradients are zero."""
+
+
+def check_replays(device=None, synchronize: bool = False):
+  """Raise ``FrameOverflow`` if a captured frame's most recent replay (of those that have finished on the GPU; all of
+  them with ``synchronize=True``) exceeded its overlap capacity.  Costs a host compare per captured frame: each frame
+  owns a pinned word its K kernel rewrites on every replay.  Called by ``FrameGraph.replay`` (before launching the
+  next replay; after it, synchronising, with ``MS_STRICT=1``), by ``LazyPoints`` and ``frame_status`` — i.e. at the
+  next host touch, so a training loop replaying an overflowed graph stops within one step instead of silently
+  training on background frames."""
+  if synchronize:
+    torch.cuda.synchronize(device)
+  alive = []
+  worst = None
+  for ref in _captured_frames:
+    st = ref()
+    if st is None:
+      continue
+    alive.append(ref)
+    if device is not None and st.keep_n is not None and st.keep_n.device != torch.device(device):
+      continue
+    k = int(st.k_view[0])
+    if k < 0 or k > st.capacity:
+      st.overflowed = max(st.overflowed, k if k >= 0 else (1 << 31) - 1)
+    if st.overflowed and (worst is None or st.overflowed > worst.overflowed):
+      worst = st
+  _captured_frames[:] = alive
+  if worst is not None:
+    need = worst.overflowed
+    worst.overflowed = 0           # reported once; the caller re-captures (or not) knowingly
+    raise FrameOverflow(
+      f"a frame replayed from a HIP graph produced {need} tile overlaps but was captured with room for "
+      f"{worst.capacity}: that replay rendered the background only and returned zero gradients.  Call "
+      f"frame.set_overlap_capacity(n, image_size, config, {int(need * K_SLACK)}) and capture the step again.")
 
 
 class _FrameFunction(torch.autograd.Function):
@@ -344,8 +476,15 @@ class _FrameFunction(torch.autograd.Function):
     es = image.element_size()
     state.desc, state.inputs, state.keep_n, state.y0 = desc, inputs, keep_n, y0
     state.tensors = tensors                                  # the pointers in `inputs` stay valid
-    _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image.data_ptr() - y0 * w * f * es,
-                     alpha.data_ptr() - y0 * w * es, visibility if config.compute_visibility else None, device,
+    if y1 > y0:
+      image_ptr, alpha_ptr = image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es
+    else:
+      # an empty cropped strip: zero-row tensors have a null data pointer, which the C entry points reject (and
+      # `0 - y0 * ...` would wrap); the raster touches no row, any valid address will do
+      state.dummy = torch.empty((16,), dtype=dtype, device=device)
+      image_ptr = alpha_ptr = state.dummy.data_ptr()
+    _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
+                     visibility if config.compute_visibility else None, device,
                      "render_gaussians", state, settle_now=opts.render_median_depth)
     layout = state.layout
 
@@ -454,10 +593,11 @@ class _FrameFunction(torch.autograd.Function):
       gr.point_heuristic = ctx.heuristic.data_ptr()
 
     try:
-      _lib.check(lib.ms_frame_backward(ctypes.byref(desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
-                                       state.keep_k.data_ptr(), ctypes.byref(gr), stream), "render_gaussians backward")
+      with _lock:       # the two launches of a backward pass are enqueued back to back (ctypes releases the GIL)
+        _lib.check(lib.ms_frame_backward(ctypes.byref(desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
+                                         state.keep_k.data_ptr(), ctypes.byref(gr), stream), "render_gaussians backward")
     except Exception:
-      _moments.clear()        # the accumulator rows may have been left half-written: start from a fresh buffer
+      _drop_moments()         # the accumulator rows may have been left half-written: start from a fresh buffer
       raise
 
     if retained:
@@ -576,11 +716,12 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     if heuristic is not None:
       gr.point_heuristic = heuristic.data_ptr()
     try:
-      _lib.check(lib.ms_frame_backward(ctypes.byref(state.desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
-                                       state.keep_k.data_ptr(), ctypes.byref(gr), _lib.current_stream(device)),
-                 "rasterize backward")
+      with _lock:
+        _lib.check(lib.ms_frame_backward(ctypes.byref(state.desc), ctypes.byref(state.inputs), state.keep_n.data_ptr(),
+                                         state.keep_k.data_ptr(), ctypes.byref(gr), _lib.current_stream(device)),
+                   "rasterize backward")
     except Exception:
-      _moments.clear()
+      _drop_moments()
       raise
     return (gp if need_points else None), None, (gf if need_features else None), None, None, None, None
 
@@ -611,6 +752,8 @@ class LazyPoints:
       mask = depth > 0
       v = int(mask.sum().item())
     point_syncs += 1
+    if state.captured:
+      check_replays(depth.device)      # the host has just synchronised: an overflowed replay is reported here
     if v == n:
       idx, sel = identity_indexes(n, depth.device), None
       g2d, dep = points7, depth.unsqueeze(1)
@@ -660,6 +803,8 @@ def frame_status(rendering) -> dict:
   state = getattr(rendering, 'frame', None)
   assert state is not None, "frame_status: not a rendering of the frame executor"
   k, live, overflow = state.counters()[:3].tolist()
+  if overflow and state.captured:
+    state.overflowed = 0               # reported here; check_replays() need not raise for it again
   return {"overlaps": k, "capacity": state.capacity, "overflow": bool(overflow)}
 
 
@@ -670,15 +815,19 @@ class FrameGraph:
   the gaussians' parameter tensors, the camera tensors and whatever the loss reads keep their storage, and new
   values (a new camera pose, updated parameters) are written into them in place between replays.  The frame executor
   never goes back to the host, so the whole step — about 35 kernel launches for forward + backward — is one graph.
-  The overlap-list capacity is the one remembered from the eager warm-up frames; ``frame_status(result)`` tells
-  whether a later replay exceeded it (the frame then holds the background only and the step must be re-captured after
-  ``set_overlap_capacity``).  Do not touch ``result.points`` inside ``step`` (it reads the visible count back), and
+  The overlap-list capacity is the one remembered from the eager warm-up frames.  A replay that exceeds it renders
+  the background only and returns zero gradients; it does NOT pass silently: every captured frame owns a pinned word
+  its K kernel rewrites on each replay, ``replay()`` compares the words with the capacities before launching the next
+  replay and raises ``FrameOverflow`` (so a training loop stops within one step of the overflow), and with
+  ``MS_STRICT=1`` (or ``strict=True``) it synchronises after the launch and raises for that very replay.
+  ``frame_status(result)`` reads the device-side counters.  Re-capture after ``set_overlap_capacity``.  Do not touch ``result.points`` inside ``step`` (it reads the visible count back), and
   drop every reference to renderings / losses of earlier eager steps first: torch's rule for whole-step capture — an
   autograd graph created on the default stream that is still alive pulls its gradient accumulation onto that stream
   and breaks the capture.
   """
 
-  def __init__(self, step, warmup: int = 2):
+  def __init__(self, step, warmup: int = 2, strict: Optional[bool] = None):
+    self.strict = STRICT if strict is None else bool(strict)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -691,5 +840,8 @@ class FrameGraph:
       self.result = step()
 
   def replay(self):
+    check_replays()                    # earlier replays that have finished: host compare only, no synchronisation
     self.graph.replay()
+    if self.strict:
+      check_replays(synchronize=True)
     return self.result

@@ -31,14 +31,17 @@ class PointState:
     return self.state[key]
 
   def moments(self, param: torch.Tensor, per_point_second_moment: bool):
-    rows = param.view(param.shape[0], -1)
-    first = self._get('v', lambda: torch.zeros_like(rows))
-    second = self._get('m', (lambda: rows.new_zeros((rows.shape[0],))) if per_point_second_moment
-                       else (lambda: torch.zeros_like(rows)))
-    return first, second
+    # the pair is created TOGETHER, keyed on the first moment alone (reference optim/util.py:5-18): a state dict
+    # restored with only 'm' gets both reset, one restored with only 'v' fails on the missing 'm' as it does there
+    if 'v' not in self.state:
+      rows = param.view(param.shape[0], -1)
+      self.state['v'] = torch.zeros_like(rows)
+      self.state['m'] = rows.new_zeros((rows.shape[0],)) if per_point_second_moment else torch.zeros_like(rows)
+    return self.state['v'], self.state['m']
 
-  def per_point(self, key: str, n: int, device) -> torch.Tensor:
-    return self._get(key, lambda: torch.zeros((n,), dtype=torch.float32, device=device))
+  def per_point(self, key: str, shape, device) -> torch.Tensor:
+    dims = tuple(shape) if isinstance(shape, (tuple, list, torch.Size)) else (int(shape),)
+    return self._get(key, lambda: torch.zeros(dims, dtype=torch.float32, device=device))
 
 
 class restore_grad:

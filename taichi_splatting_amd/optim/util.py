@@ -20,8 +20,8 @@ def get_total_weight(state: dict, n: int, device: torch.device):
 
 
 def get_running_vis(state: dict, shape, device: torch.device):
-  n = shape[0] if isinstance(shape, (tuple, list, torch.Size)) else int(shape)
-  return PointState(state).per_point('running_vis', n, device)
+  """zeros(shape) on first use — the whole shape, as the reference allocates it (optim/util.py:28-32)"""
+  return PointState(state).per_point('running_vis', shape, device)
 
 
 def flatten_param(param: torch.Tensor):

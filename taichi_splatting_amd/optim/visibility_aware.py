@@ -11,35 +11,26 @@ import torch
 from .fractional import ADAM, LAPROP, PointState, fused_update, make_group, saturate, weighted_step  # noqa: F401
 
 
-def lerp(t, a, b):
-  return a + (b - a) * t
+def _track_visibility(running: torch.Tensor, seen: torch.Tensor, indexes: torch.Tensor, beta: float,
+                      order: int = 4, floor: float = 1e-12) -> torch.Tensor:
+  """Fold this step's visibilities into the running ones and return each point's step weight.
 
-
-def power_lerp(t, a, b, k=2):
-  return lerp(t, a ** k, b ** k) ** (1 / k)
-
-
-def update_visibility(running_vis: torch.Tensor, visibility: torch.Tensor, indexes: torch.Tensor,
-                      total_weight: torch.Tensor, beta: float = 0.9, eps: float = 1e-12):
-  updated_vis = power_lerp(beta, visibility, running_vis[indexes], k=4)
-  running_vis[indexes] = updated_vis
-  return visibility / torch.clamp_min(updated_vis, eps)
-
-
-def set_indexes(target: torch.Tensor, values: torch.Tensor, indexes: torch.Tensor):
-  result = torch.zeros_like(target)
-  result[indexes] = values
-  return result
+  The running value is an exponential moving POWER mean (order 4, i.e. biased towards a point's better views):
+  ``r <- ((1 - beta) v^4 + beta r^4)^(1/4)`` for the points listed in ``indexes``; the weight is the visibility
+  relative to it, ``v / max(r, floor)`` (reference optim/visibility_aware.py:25-41)."""
+  previous = running[indexes]
+  mixed = (seen ** order + (previous ** order - seen ** order) * beta) ** (1 / order)
+  running[indexes] = mixed
+  return seen / torch.clamp_min(mixed, floor)
 
 
 class VisibilityOptimizer(torch.optim.Optimizer):
   def __init__(self, kind: int, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, vis_beta=0.9,
                vis_smooth: float = 0.01, bias_correction=True, grad_clip: Optional[float] = None):
-    assert lr > 0, f"Invalid learning rate: {lr}"
-    assert eps > 0, f"Invalid epsilon: {eps}"
-    assert 0.0 <= betas[0] < 1.0, f"Invalid beta1: {betas[0]}"
-    assert 0.0 <= betas[1] < 1.0, f"Invalid beta2: {betas[1]}"
-    assert 0.0 <= vis_beta < 1.0, f"Invalid visibility beta: {vis_beta}"
+    for name, value, ok in (("lr", lr, lr > 0), ("eps", eps, eps > 0), ("betas[0]", betas[0], 0.0 <= betas[0] < 1.0),
+                            ("betas[1]", betas[1], 0.0 <= betas[1] < 1.0), ("vis_beta", vis_beta, 0.0 <= vis_beta < 1.0)):
+      if not ok:
+        raise AssertionError(f"VisibilityOptimizer: {name} = {value} is out of range")
     defaults = dict(lr=lr, betas=betas, eps=eps, mask_lr=None, point_lr=None, type="scalar",
                     bias_correction=bias_correction, clip=grad_clip)
     self.vis_beta = vis_beta
@@ -57,7 +48,7 @@ class VisibilityOptimizer(torch.optim.Optimizer):
     total_weight = shared.per_point('total_weight', n, visibility.device)
     running_vis = shared.per_point('running_vis', n, visibility.device)
 
-    weight = update_visibility(running_vis, visibility, indexes, total_weight, self.vis_beta)
+    weight = _track_visibility(running_vis, visibility, indexes, self.vis_beta)
     total_weight[indexes] += weight
 
     grad_scale = 1.0 / (visibility + self.vis_smooth)

@@ -16,7 +16,9 @@ so that a rank enqueues a whole step ahead of its GPU and the step can be captur
 What the step of ``distributed.render_sharded_step`` had to wait for — the visible count, the all-to-all split sizes,
 the overlap total — stays on the device here: nothing is compacted, bucket and overlap-list capacities are fixed by
 ``probe()`` (a synchronising dry run outside the hot loop, like the strip bounds) and overflow only raises device-side
-flags that ``check()`` reads whenever the caller chooses to synchronise.
+flags.  The flags (and each strip's overlap total) are written through PINNED host words: ``step()`` compares them on
+entry without synchronising and raises ``frame.FrameOverflow`` one step after an overflow; ``MS_STRICT=1``
+synchronises inside the step and raises for that step; ``check()`` reads the device counters (synchronises).
 """
 from __future__ import annotations
 
@@ -130,7 +132,14 @@ class _RankStep:
     self.px_rows = (min(self.rows[0] * ts, h), min(self.rows[1] * ts, h))
     self.k_capacity = 0
     self.timer = StageTimer(time_stages)
-    self.flags = None            # device int32[2]: bucket overflow, (unused)
+    # Overflow indicators live in PINNED HOST memory the kernels write through (like the eager frame's K word): the
+    # host compares them without touching the device, so an overflowed step is reported at the next step() — never a
+    # silent run of background-only strips.  flags[0] = bucket overflow (sticky: only ever set), k_word = overlap total
+    # of the last strip frame.
+    self.flags = torch.zeros((2,), dtype=torch.int32).pin_memory()
+    self.k_word = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    self._flags_np, self._k_np = self.flags.numpy(), self.k_word.numpy()
+    self.strict = frame.STRICT
     self.last_counters = None    # counters view of the last strip frame
     self.comm_bytes = {}
 
@@ -142,15 +151,22 @@ class _RankStep:
     keep_n, scratch_n = _block(lay.keep_n_bytes, device), _block(lay.scratch_n_bytes, device)
     keep_k, scratch_k = _block(lay.keep_k_bytes, device), _block(lay.scratch_k_bytes, device)
     _lib.check(lib.ms_frame_project_count(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
-                                          None, None, stream), "rank step (map)")
+                                          self.k_word.data_ptr(), None, stream), "rank step (map)")
     w = self.image_size[0]
     y0, y1 = self.px_rows
     image = torch.empty((y1 - y0, w, f), dtype=dtype, device=device)
     alpha = torch.empty((y1 - y0, w), dtype=dtype, device=device)
     es = image.element_size()
+    if y1 > y0:
+      image_ptr, alpha_ptr = image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es
+    else:
+      # an empty strip (bounds may repeat a value): the mapper still runs (capacity, counters), the raster touches no
+      # row; zero-row tensors have a null data pointer, which the C entry points reject
+      self._dummy = torch.empty((16,), dtype=dtype, device=device)
+      image_ptr = alpha_ptr = self._dummy.data_ptr()
     _lib.check(lib.ms_frame_map_raster(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), scratch_n.data_ptr(),
-                                       keep_k.data_ptr(), scratch_k.data_ptr(), image.data_ptr() - y0 * w * f * es,
-                                       alpha.data_ptr() - y0 * w * es, None, stream), "rank step (raster)")
+                                       keep_k.data_ptr(), scratch_k.data_ptr(), image_ptr, alpha_ptr, None, stream),
+               "rank step (raster)")
     self.last_counters = keep_n[lay.counters:lay.counters + 32].view(torch.int32)
     return lay, keep_n, keep_k, image, alpha
 
@@ -169,10 +185,54 @@ class _RankStep:
   def check(self) -> dict:
     """Host read (synchronises) of the device-side overflow flags of the LAST step."""
     k, live, over = (self.last_counters[:3].tolist() if self.last_counters is not None else (0, 0, 0))
-    out = {"overlaps": k, "overlap_capacity": self.k_capacity, "overlap_overflow": bool(over)}
-    if self.flags is not None:
-      out["bucket_overflow"] = bool(int(self.flags[0].item()))
+    if self.last_counters is None:
+      torch.cuda.synchronize()
+    out = {"overlaps": k, "overlap_capacity": self.k_capacity, "overlap_overflow": bool(over),
+           "bucket_overflow": bool(int(self._flags_np[0]))}
     return out
+
+  def poll(self):
+    """Raise ``frame.FrameOverflow`` if a finished step exceeded a capacity (no synchronisation: pinned words).
+    ``step()`` calls it on entry, so a loop of sync-free / graph-replayed steps stops at the step after the overflow;
+    with ``MS_STRICT=1`` (``self.strict``) the step synchronises and raises for itself."""
+    k = int(self._k_np[0])
+    if self._flags_np[0]:
+      self._flags_np[0] = 0
+      raise frame.FrameOverflow(f"rank {self.rank}: a destination bucket of the splat exchange overflowed (capacity "
+                                f"{getattr(self, 'bucket_capacity', 0)} rows): splats were dropped from a strip.  probe() again "
+                                "(larger slack) before the next step.")
+    if self.k_capacity > 0 and (k < 0 or k > self.k_capacity):
+      self._k_np[0] = 0
+      raise frame.FrameOverflow(f"rank {self.rank}: the strip produced {k} tile overlaps, its buffers hold {self.k_capacity}: "
+                                "that step rendered the background only and returned zero gradients.  probe() again "
+                                "(larger slack) before the next step.")
+
+  def _enter_step(self, gaussians, camera_params):
+    self.poll()
+    for t in (camera_params.T_camera_world, camera_params.projection):
+      if t.requires_grad:
+        raise NotImplementedError("rank steps do not produce camera gradients (T_camera_world / projection require grad): "
+                                  "the per-gaussian pass of a rank sees only its shard / strip; use render_gaussians on one GPU "
+                                  "for pose optimisation")
+
+  def _leave_step(self):
+    if self.strict and not torch.cuda.is_current_stream_capturing():
+      torch.cuda.synchronize()
+      self.poll()
+
+  def _raster_backward_mode(self, lib, desc, gr, g_image, device, rows_n):
+    """moments path + deterministic commits as frame.py does it (``rasterizer.function.DETERMINISTIC_BACKWARD`` /
+    MS_DETERMINISTIC is honoured on the rank steps too)"""
+    from .rasterizer import function as raster_function
+    det = bool(raster_function.DETERMINISTIC_BACKWARD)
+    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), int(det)))
+    if moments_path:
+      gr.moments = frame._moments_buffer(device, rows_n, det).data_ptr()
+      gr.deterministic = int(det)
+      if det:
+        self._fixed_exp = _lib.fixed_point_exponents(g_image)
+        gr.fixed_exp = self._fixed_exp.data_ptr()
+    return moments_path, det
 
 
 class StripStep(_RankStep):
@@ -194,6 +254,7 @@ class StripStep(_RankStep):
   def step(self, gaussians: Gaussians3D, camera_params: CameraParams, loss_fn: Callable, use_sh: bool = True,
            backward: bool = True):
     assert self.k_capacity > 0, "StripStep.probe() first (fixes the overlap-list capacity)"
+    self._enter_step(gaussians, camera_params)
     lib = _lib.load()
     tensors = [t.detach().contiguous() for t in (*gaussians.shape_tensors(), gaussians.feature,
                                                  camera_params.T_camera_world.reshape(4, 4), camera_params.projection.reshape(4))]
@@ -213,10 +274,12 @@ class StripStep(_RankStep):
     loss, g_image = self._loss_and_image_grad(image, loss_fn, backward)
     timer.mark('loss')
     if not backward:
+      self._leave_step()
       return image.detach(), loss
 
     # raster backward of the strip -> (n, 7 + f) 2D-boundary gradients -> sum over the strips
-    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), 0))
+    gr = _lib.FrameGradsC()
+    moments_path, det = self._raster_backward_mode(lib, desc, gr, g_image, device, n)
     width = 7 + f
     rows = (n + self.world - 1) // self.world * self.world
     es = image.element_size()
@@ -232,13 +295,10 @@ class StripStep(_RankStep):
     else:
       gp = torch.empty((n, 7), dtype=dtype, device=device) if moments_path else torch.zeros((n, 7), dtype=dtype, device=device)
       gc = torch.empty((n, f), dtype=dtype, device=device) if moments_path else torch.zeros((n, f), dtype=dtype, device=device)
-    gr = _lib.FrameGradsC()
     y0 = self.px_rows[0]
     row_bytes = y0 * self.image_size[0] * es
     gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
     gr.stage = _lib.BACKWARD_RASTER
-    if moments_path:
-      gr.moments = frame._moments_buffer(device, n, False).data_ptr()
     if in_place:
       gr.grad_points7, gr.grad_colours, gr.boundary_stride = buf.data_ptr(), buf.data_ptr() + 7 * es, width
     else:
@@ -280,6 +340,7 @@ class StripStep(_RankStep):
     timer.mark('gaussian_bwd')
     for leaf, g in zip((*gaussians.shape_tensors(), gaussians.feature), (*grads, grad_feature)):
       _accumulate(leaf, g)
+    self._leave_step()
     return image.detach(), loss
 
 
@@ -321,6 +382,7 @@ class ShardedStep(_RankStep):
   def step(self, shard: Gaussians3D, camera_params: CameraParams, loss_fn: Callable, use_sh: bool = True,
            backward: bool = True):
     assert self.k_capacity > 0 and self.bucket_capacity > 0, "ShardedStep.probe() first (fixes the capacities)"
+    self._enter_step(shard, camera_params)
     lib = _lib.load()
     tensors = [t.detach().contiguous() for t in (*shard.shape_tensors(), shard.feature,
                                                  camera_params.T_camera_world.reshape(4, 4), camera_params.projection.reshape(4))]
@@ -360,8 +422,6 @@ class ShardedStep(_RankStep):
     width = 9 + f
     send = torch.zeros((m, width), dtype=dtype, device=device)
     send_index = torch.full((m,), -1, dtype=torch.int64, device=device)
-    if self.flags is None:
-      self.flags = torch.zeros((2,), dtype=torch.int32, device=device)
     # slots[i, c] = row of the send buffer that carries copy c of gaussian i: where its gradient comes back
     slots = torch.empty((max(n, 1), world), dtype=torch.int32, device=device)
     if n > 0:
@@ -393,11 +453,12 @@ class ShardedStep(_RankStep):
     self.comm_bytes = {"all_to_all_forward_bytes": m * width * es, "all_to_all_backward_bytes": m * (7 + f) * es if backward else 0,
                        "bucket_capacity_rows": cap, "off_chip_fraction": (world - 1) / world}
     if not backward:
+      self._leave_step()
       return image.detach(), loss
 
     # ---- backward: strip raster -> gradients of the received rows -> home -> per-gaussian pass ---------------------
-    moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc_b), 0))
     gr = _lib.FrameGradsC()
+    moments_path, det = self._raster_backward_mode(lib, desc_b, gr, g_image, device, m)
     row_bytes = self.px_rows[0] * self.image_size[0] * es
     gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
     gr.stage = _lib.BACKWARD_RASTER
@@ -405,7 +466,6 @@ class ShardedStep(_RankStep):
     if moments_path:
       # the finalize pass stores [d packed 2D | d colour] straight into the rows of the return buffer
       back_send = torch.empty((m, bw), dtype=dtype, device=device)
-      gr.moments = frame._moments_buffer(device, m, False).data_ptr()
       gr.grad_points7, gr.grad_colours = back_send.data_ptr(), back_send.data_ptr() + 7 * es
       gr.boundary_stride = bw
     else:
@@ -452,4 +512,5 @@ class ShardedStep(_RankStep):
     timer.mark('return_gaussian_bwd')
     for leaf, g in zip((*shard.shape_tensors(), shard.feature), (*grads, grad_feature)):
       _accumulate(leaf, g)
+    self._leave_step()
     return image.detach(), loss
