@@ -149,3 +149,50 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     tile_ranges: (TH, TW, 2) int32, tile -> [start, end) range of overlap indices
   """
   return map_to_tiles_strip(gaussians, depth, image_size, config, use_depth16=use_depth16)
+
+
+def with_reference_tail(overlap_to_point: torch.Tensor, tile_ranges: torch.Tensor, tile_size: int,
+                        group: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+  """DEBUG AID, forward only: tile lists extended so that the kernels visit splats in the order the REFERENCE's
+  kernels do, including the revisits caused by its in-group loop bound.
+
+  The reference walks a tile's list in groups of ``group`` = tile_size^2 splats staged in shared memory, with the
+  in-group bound ``min(group, count - group_index)`` where ``count - group_index * group`` is meant
+  (``rasterizer/forward.py:86-89``): after the valid entries of the LAST, partially filled group it keeps going and
+  blends again whatever the PREVIOUS group left in shared memory at those slots.  This library visits every splat
+  exactly once, so on tiles with more than ``group`` splats its image differs from Taichi's output (config-D
+  density: 57 % of the pixels by more than 1e-4, at most 5.6e-2).  To diff against an image
+  rendered by the reference, rasterize with the lists returned here::
+
+      o2p, ranges = map_to_tiles(gaussians2d, depths, image_size, config)
+      o2p_ref, ranges_ref = with_reference_tail(o2p, ranges, config.tile_size)
+      image_like_taichi = rasterize_with_tiles(gaussians2d, features, o2p_ref, ranges_ref.view(-1, 2),
+                                               image_size, config).image          # under torch.no_grad()
+
+  Forward only: the reference drops the gradients of the revisited entries (``backward.py:214``) while a backward pass
+  over these lists would count them.  Pure index arithmetic on the device (no kernel of its own)."""
+  assert overlap_to_point.dtype == torch.int32 and tile_ranges.dtype == torch.int32
+  g = int(group) if group is not None else int(tile_size) * int(tile_size)
+  shape = tile_ranges.shape
+  r = tile_ranges.reshape(-1, 2).long()
+  start, count = r[:, 0], r[:, 1] - r[:, 0]
+  last = torch.clamp(count - 1, min=0) // g                     # index of the last group
+  valid = count - last * g                                      # its valid entries
+  visited = torch.minimum(torch.full_like(count, g), count - last)
+  tail = torch.where(last > 0, torch.clamp(visited - valid, min=0), torch.zeros_like(count))
+  new_count = count + tail
+  new_end = torch.cumsum(new_count, dim=0)
+  new_start = new_end - new_count
+  total = int(new_end[-1].item()) if new_end.numel() else 0
+  out = torch.empty((total,), dtype=torch.int32, device=overlap_to_point.device)
+  if total:
+    tile = torch.repeat_interleave(torch.arange(r.shape[0], device=r.device), new_count)
+    k = torch.arange(total, device=r.device) - new_start[tile]
+    # k < count: the list itself; beyond it: slot (valid + k - count) of the previous group
+    stale = (last[tile] - 1) * g + valid[tile] + (k - count[tile])
+    src = start[tile] + torch.where(k < count[tile], k, stale)
+    out = overlap_to_point[src]
+  # empty tiles keep [0, 0) like find_ranges
+  new_ranges = torch.stack([torch.where(new_count > 0, new_start, torch.zeros_like(new_start)),
+                            torch.where(new_count > 0, new_end, torch.zeros_like(new_end))], dim=1).to(torch.int32)
+  return out, new_ranges.reshape(shape)

@@ -248,3 +248,31 @@ def test_empty_strip_is_a_valid_rank():
   # the single-process frame with an empty cropped strip
   r = frame.render_frame(g, cam, cfg, True, tile_rows=(5, 5), crop_to_rows=True)
   assert r.image.shape[0] == 0
+
+
+@pytest.mark.parametrize('tile_size', [8, 16])
+def test_reference_tail_lists_reproduce_the_reference_loop_order(tile_size):
+  """with_reference_tail(): a user diffing against Taichi output gets the reference's visiting order (fact 8) from
+  the product kernels — float64 against the oracle's emulation of forward.py:86-89."""
+  from oracle import mapper as omap, raster as orast
+  from taichi_splatting_amd import rasterize_with_tiles
+  from taichi_splatting_amd.mapper.tile_mapper import with_reference_tail
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  size = (96, 64)
+  cfg = RasterConfig(tile_size=tile_size, pixel_stride=(1, 1) if tile_size == 8 else (2, 2))
+  torch.manual_seed(tile_size)
+  g = random_2d_gaussians(6000, size, scale_factor=4.0, alpha_range=(0.02, 0.3))       # several groups per tile
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy().astype('float32'), g.depths.numpy(), size, tile_size)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  counts = (ranges[..., 1] - ranges[..., 0]).flatten()
+  assert int((counts > tile_size * tile_size).sum()) > 0
+  plain, _, _ = orast.forward(p, f, ranges, o2p, size, cfg)
+  want, want_alpha, _ = orast.forward(p, f, ranges, o2p, size, cfg, emulate_reference_loop_bound=True)
+  assert float((plain - want).abs().max()) > 1e-4, "the scene must show the deviation"
+  o2p_ref, ranges_ref = with_reference_tail(o2p.to(DEV), ranges.to(DEV), tile_size)
+  with torch.no_grad():
+    out = rasterize_with_tiles(p.to(DEV), f.to(DEV), o2p_ref, ranges_ref.view(-1, 2), size, cfg)
+  assert torch.allclose(out.image.cpu(), want, atol=1e-9)
+  assert torch.allclose(out.image_weight.cpu(), want_alpha, atol=1e-9)
