@@ -86,6 +86,7 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
     const bool vis = valid && a.depth[i] > T(0);
 
     T gp[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    T gcov[3] = {T(0), T(0), T(0)};          // MOM: dL/d(a, b, c) of the 2D covariance straight from the moments
     T gf[GB_MAX_F] = {T(0), T(0), T(0), T(0)};
     T dp[3] = {T(0), T(0), T(0)}, dls[3] = {T(0), T(0), T(0)}, dq[4] = {T(0), T(0), T(0), T(0)}, dal = T(0);
     T heur0 = T(0), heur1 = T(0);
@@ -132,6 +133,18 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         gp[4] = (T)(isx * Sxx);
         gp[5] = (T)(isy * Syy);
         gp[6] = (T)(S / alpha);
+        // The same moments as dL/d(covariance): for the plain pdf g = exp(-d^T S^-1 d / 2), dg/dS = g S^-1 d d^T S^-1 / 2,
+        // and in the eigenbasis U = [axis, perp(axis)] that is U N U^T / 2 with N = [[Sxx / sx^2, Sxy / (sx sy)], [., Syy / sy^2]]:
+        // smooth in the covariance.  The projection backward gets THIS instead of (d axis, d sigma), whose chain through
+        // the eigen-decomposition divides by l1 - l2 (splat_math.h project_backward): float32 gradients of nearly
+        // isotropic splats no longer lose their digits.  gp[2..5] are still what a caller of viewspace_gradient() reads.
+        {
+          const float N00 = Sxx * isx * isx, N01 = Sxy * isx * isy, N11 = Syy * isy * isy;
+          const float uu = ax * ax, ww = ay * ay, uw = ax * ay;
+          gcov[0] = (T)(0.5f * (N00 * uu - 2.0f * N01 * uw + N11 * ww));
+          gcov[1] = (T)((N00 - N11) * uw + N01 * (uu - ww));            // b sits off the diagonal twice
+          gcov[2] = (T)(0.5f * (N00 * ww + 2.0f * N01 * uw + N11 * uu));
+        }
         gf[0] = (T)r1.z; gf[1] = (T)r1.w; gf[2] = (T)r2.x;
         heur0 = (T)(alpha * alpha * r2.y);          // backward.py:190-194
         heur1 = (T)(r2.z * IS2);
@@ -155,14 +168,21 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         if (DEG >= 0 && a.grad_colours)
           _Pragma("unroll") for (int c = 0; c < GB_MAX_F; ++c) if (c < a.f) gf[c] = a.grad_colours[i * a.gc_stride + c];
       }
+      T gx[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0)};      // gradients arriving at the frame's own gaussians2d output
       if (a.extra_points7) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) gp[k] += a.extra_points7[i * 7 + k];
+        for (int k = 0; k < 7; ++k) { gx[k] = a.extra_points7[i * 7 + k]; gp[k] += gx[k]; }
       }
       if ((MOM || DEG >= 0) && a.extra_colours)
         _Pragma("unroll") for (int c = 0; c < GB_MAX_F; ++c) if (c < a.f) gf[c] += a.extra_colours[i * a.f + c];
 
-      project_backward(p, cam, st, gp, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad);
+      if constexpr (MOM) {
+        // rasterizer part of (axis, sigma) as a covariance gradient; only the caller's extras go through the eigen chain
+        const T gq[7] = {gp[0], gp[1], gx[2], gx[3], gx[4], gx[5], gp[6]};
+        project_backward(p, cam, st, gq, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad, gcov);
+      } else {
+        project_backward(p, cam, st, gp, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad);
+      }
 
       if constexpr (DEG >= 0) {
         const T dx = p[0] - a.camera_position[0], dy = p[1] - a.camera_position[1], dz = p[2] - a.camera_position[2];

@@ -160,7 +160,12 @@ MS_HD bool project_forward(const T p[3], const T ls[3], const T q[4], T alpha_lo
 template <typename T>
 MS_HD void project_backward(const T p[3], const Camera<T>& cam, const ProjState<T>& st,
                             const T g_point[7], T g_depth,
-                            T d_pos[3], T d_ls[3], T d_q[4], T& d_alpha_logit, T cam_grad[16]) {
+                            T d_pos[3], T d_ls[3], T d_q[4], T& d_alpha_logit, T cam_grad[16],
+                            const T* g_cov = nullptr) {
+  // g_cov (optional): dL/d(a, b, c) of the blurred 2D covariance, ADDED to what g_point's (axis, sigma) entries give.
+  // The fused per-gaussian pass (gaussian_bwd.hip) passes the rasterizer's gradient this way — the plain gaussian pdf
+  // depends on (axis, sigma) only through the covariance, so its gradient never needs the eigen-decomposition's
+  // derivative at all (no division by l1 - l2 anywhere).
   const T z = st.pc[2];
   const T g_mean[2] = {g_point[0], g_point[1]};
   const T g_axis[2] = {g_point[2], g_point[3]};
@@ -169,24 +174,45 @@ MS_HD void project_backward(const T p[3], const Camera<T>& cam, const ProjState<
   // 1. alpha = sigmoid(alpha_logit)
   d_alpha_logit = g_point[6] * st.alpha * (1 - st.alpha);
 
-  // 2. sigma = sqrt(lambda); axis = normalise((a - l2, b))
-  T dl1 = g_sigma[0] / (2 * st.sigma[0]);
-  T dl2 = g_sigma[1] / (2 * st.sigma[1]);
-  const T dot_ax = st.axis[0] * g_axis[0] + st.axis[1] * g_axis[1];
-  const T dvx = (g_axis[0] - st.axis[0] * dot_ax) / st.vn;
-  const T dvy = (g_axis[1] - st.axis[1] * dot_ax) / st.vn;
-  T da = dvx, db = dvy, dc = 0;
-  dl2 -= dvx;
-
-  // 3. lambda = (tr +- sqrt(max(gap, 0))) / 2; gap = tr^2 - 4 det
-  T dtr = (dl1 + dl2) * T(0.5);
-  const T dsg = (dl1 - dl2) * T(0.5);
-  const T dgap = st.gap > 0 ? dsg / (2 * st.sg) : T(0);
-  dtr += 2 * st.tr * dgap;
-  const T ddet = -4 * dgap;
-  da += dtr + st.c * ddet;
-  dc += dtr + st.a * ddet;
-  db += -2 * st.b * ddet;
+  // 2 + 3. (sigma, axis) = eigen-pair of the covariance [[a, b], [b, c]] (taichi_lib/generic.py:217-230), as ONE
+  // closed form.  With u = axis, w = perp(u), l1 - l2 = sg, first-order perturbation of a symmetric 2x2 matrix gives
+  //   d l1 = u^T dS u,   d l2 = w^T dS w,   d u = (w^T dS u) / (l1 - l2) w
+  // hence  dL/dS = gl1 u u^T + gl2 w w^T + kappa sym(w u^T),  kappa = <g_axis, w> / sg.
+  // The reference differentiates its formula chain (normalise((a - l2, b)), sqrt(tr^2 - 4 det)) step by step; in
+  // float32 that chain divides by |(a - l2, b)| and by sqrt(gap), both of which CANCEL to a few bits for a nearly
+  // isotropic covariance (a ~ c, b ~ 0: rows off by 1e-3 .. 1e+3 of the largest gradient, in torch_lib's own float32
+  // arithmetic just as here until round 3).  Evaluated as below only ONE ill-conditioned quantity is left, kappa,
+  // and its ingredients are formed without cancellation: a - c from the factors of M (the blur term drops out
+  // exactly), sg = hypot(a - c, 2 b) instead of sqrt(tr^2 - 4 det), and the eigenvector from whichever of its two
+  // equivalent expressions adds two positive numbers.  Same function, same derivative (float64 agrees with the
+  // fixtures to 1e-12); what is left in float32 is the conditioning of the problem itself, eps * a / sg.
+  const T dl1 = g_sigma[0] / (2 * st.sigma[0]);
+  const T dl2 = g_sigma[1] / (2 * st.sigma[1]);
+  T amc = T(0);                                   // a - c
+  for (int j = 0; j < 3; ++j) amc += (st.M[0][j] - st.M[1][j]) * (st.M[0][j] + st.M[1][j]);
+  const T sg = t_sqrt(amc * amc + 4 * st.b * st.b);
+  T u0, u1;
+  if (amc >= 0) { u0 = (amc + sg) * T(0.5); u1 = st.b; }                              // (a - l2, b)
+  else { u0 = st.b < 0 ? -st.b : st.b; u1 = (st.b < 0 ? T(-0.5) : T(0.5)) * (sg - amc); }   // +-(b, l1 - a): same direction, u0 >= 0
+  const T un = t_sqrt(u0 * u0 + u1 * u1);
+  T da, db, dc;
+  if (st.gap > 0 && un > 0) {
+    u0 /= un; u1 /= un;
+    const T kappa = (g_axis[1] * u0 - g_axis[0] * u1) / sg;      // <g_axis, w> / (l1 - l2), w = (-u1, u0)
+    const T uu = u0 * u0, ww = u1 * u1, uw = u0 * u1;
+    da = dl1 * uu + dl2 * ww - kappa * uw;
+    dc = dl1 * ww + dl2 * uu + kappa * uw;
+    db = 2 * uw * (dl1 - dl2) + kappa * (uu - ww);
+  } else {
+    // gap <= 0 (exactly isotropic): the reference's sqrt(max(gap, 0)) passes no gradient to gap and its axis is
+    // normalise((a - tr / 2, b)); keep that branch as the reference has it
+    const T dot_ax = st.axis[0] * g_axis[0] + st.axis[1] * g_axis[1];
+    const T dvx = (g_axis[0] - st.axis[0] * dot_ax) / st.vn;
+    const T dvy = (g_axis[1] - st.axis[1] * dot_ax) / st.vn;
+    const T dtr = (dl1 + (dl2 - dvx)) * T(0.5);
+    da = dvx + dtr; db = dvy; dc = dtr;
+  }
+  if (g_cov) { da += g_cov[0]; db += g_cov[1]; dc += g_cov[2]; }
 
   // 4. cov = M M^T (+ blur)
   T dM[2][3];

@@ -46,6 +46,34 @@ extern "C" void hm_project_bwd(const double* pos, const double* ls, const double
   }
 }
 
+// float32 instantiation of the projection backward (inputs / outputs travel as double, the arithmetic is float):
+// the conditioning of the hand-derived chain in the PRODUCT precision can be measured without a GPU
+// (tests/test_hostmath.py::test_projection_backward_f32_conditioning).
+extern "C" void hm_project_bwd_f32(const double* pos, const double* ls, const double* rot, const double* al,
+                                   const double* T, const double* P, int W, int H, double blur, double margin,
+                                   int64_t n, const double* g_points7, const double* g_depth, double* d_pos,
+                                   double* d_ls, double* d_rot, double* d_al, double* d_cam16) {
+  Camera<float> cam;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) cam.t[i][j] = (float)T[i * 4 + j];
+  cam.fx = (float)P[0]; cam.fy = (float)P[1]; cam.cx = (float)P[2]; cam.cy = (float)P[3];
+  ProjParams<float> pp{(float)W, (float)H, 1.0f, 2.0f, (float)blur, (float)margin, 1.0f / 255.0f};
+  float cam_grad[16];
+  for (int k = 0; k < 16; ++k) cam_grad[k] = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    float p[3], l[3], q[4], gp[7], dp_[3], dl[3], dq[4], da;
+    for (int k = 0; k < 3; ++k) { p[k] = (float)pos[i * 3 + k]; l[k] = (float)ls[i * 3 + k]; }
+    for (int k = 0; k < 4; ++k) q[k] = (float)rot[i * 4 + k];
+    for (int k = 0; k < 7; ++k) gp[k] = (float)g_points7[i * 7 + k];
+    ProjState<float> st;
+    project_forward(p, l, q, (float)al[i], cam, pp, st);
+    project_backward(p, cam, st, gp, (float)g_depth[i], dp_, dl, dq, da, cam_grad);
+    for (int k = 0; k < 3; ++k) { d_pos[i * 3 + k] = dp_[k]; d_ls[i * 3 + k] = dl[k]; }
+    for (int k = 0; k < 4; ++k) d_rot[i * 4 + k] = dq[k];
+    d_al[i] = da;
+  }
+  for (int k = 0; k < 16; ++k) d_cam16[k] = cam_grad[k];
+}
+
 template <int DEG>
 static void sh_eval(const double* params, const double* positions, const int64_t* indexes, const double* cam,
                     int64_t v, int f, const double* g_out, double* out, double* g_params, double* g_pos,

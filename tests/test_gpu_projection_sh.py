@@ -18,14 +18,15 @@ def assert_f32_gradient_as_accurate_as_reference(got, w64, w32, what):
   """got: float32 kernel result; w64 / w32: the oracle evaluated in float64 / in float32 (torch CPU) on the same
   float32 inputs.  Errors are per row (per gaussian), relative to the largest float64 gradient.
 
-  The projection backward of the reference is ill-conditioned in float32 for a fraction of a percent of the
-  gaussians (eigen-decomposition of a nearly isotropic blurred 2D covariance, quaternion normalisation): on those
-  rows torch_lib's own formulas evaluated in float32 miss the float64 value by anything from 1e-3 to 1e+3 times the
-  largest gradient (tools/diag/proj_f32_grad_error.py prints both distributions).  No float32
-  implementation can be held to 1e-4 there, so the float32 kernels are held to the north_star's 1e-4 on >= 99 % of
-  the rows and, everywhere, to the accuracy the reference arithmetic itself reaches at this precision:
-    * at least 99 % of the rows within 1e-4, and no fewer than the float32 oracle (- 0.5 %);
-    * median error below 1e-6; the 99th percentile no more than 2x the float32 oracle's (+ 1e-6);
+  torch_lib's own formulas evaluated in float32 miss the float64 value on a fraction of a per cent of the gaussians by
+  anything from 1e-3 to 1e+3 times the largest gradient: the derivative of the eigen-decomposition divides by
+  l1 - l2 and by |(a - l2, b)|, which cancel for a nearly isotropic blurred covariance
+  (tools/diag/proj_f32_grad_error.py).  Rounds 1-3 matched that conditioning; since round 4 ``project_backward``
+  evaluates the eigen-pair derivative in closed form (csrc/splat_math.h), so the float32 kernels are held to the
+  north_star's 1e-4 itself and must BEAT the reference arithmetic where that one breaks down:
+    * at least 99.9 % of the rows within 1e-4 (measured: all of them, largest 4e-5), none beyond 1e-3, and never
+      fewer rows within 1e-4 than the float32 oracle;
+    * median error below 1e-6; the 99th percentile no more than the float32 oracle's (+ 1e-6);
     * sums over all gaussians (camera gradients): no more than 5x the float32 oracle's error (+ 1e-5)."""
   got, w32 = got.double(), w32.double()
   scale = w64.abs().max().item()
@@ -38,10 +39,11 @@ def assert_f32_gradient_as_accurate_as_reference(got, w64, w32, what):
   touched = rows(w64) > 0                            # culled gaussians have zero gradient everywhere
   err, ref = err[touched], ref[touched]
   frac, frac_ref = (err <= 1e-4).double().mean().item(), (ref <= 1e-4).double().mean().item()
-  assert frac >= 0.99 and frac >= frac_ref - 0.005, (what, 'rows within 1e-4', frac, frac_ref)
+  assert frac >= 0.999 and frac >= frac_ref, (what, 'rows within 1e-4', frac, frac_ref)
+  assert err.max().item() <= 1e-3, (what, 'worst row', err.max().item(), ref.max().item())
   assert err.median().item() < 1e-6, (what, 'median', err.median().item())
   q99, q99_ref = err.quantile(0.99).item(), ref.quantile(0.99).item()
-  assert q99 <= 2 * q99_ref + 1e-6, (what, '99th percentile', q99, q99_ref)
+  assert q99 <= q99_ref + 1e-6, (what, '99th percentile', q99, q99_ref)
 
 
 def _eval_with_grad(f, *args):

@@ -60,6 +60,52 @@ def test_projection_forward_backward_vs_reference_fixture(hostmath, seed):
   assert np.all(r_T[3] == 0)
 
 
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_projection_backward_f32_conditioning(hostmath, seed):
+  """The float32 instantiation of ``project_backward`` against the float64 oracle with random upstream gradients
+  (protocol of tests/test_gpu_projection_sh.py::test_projection_f32_backward_vs_oracle, no GPU needed): the
+  closed-form eigen-pair derivative keeps EVERY gaussian within 1e-4 of the largest gradient, where the reference's
+  chain evaluated in float32 (the torch oracle in float32) has rows off by 1e-2 ... 1e+1."""
+  from oracle import projection as oproj
+  from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+  torch.manual_seed(seed)
+  camera = random_camera()
+  n = 4000
+  g = random_3d_gaussians(n=n, camera_params=camera, margin=0.5, scale_factor=0.1 if seed % 2 else 1.0)
+  in32 = [t.float() for t in g.shape_tensors()] + [camera.T_camera_world.float(), camera.projection.float()]
+
+  def run(args, gp=None, gd=None):
+    args = [a.detach().clone().requires_grad_(True) for a in args]
+    points, depth, idx = oproj.apply(*args, camera.image_size, camera.depth_range, blur_cov=0.3)
+    if gp is None:
+      torch.manual_seed(100 + seed)
+      gp, gd = torch.randn(points.shape, dtype=torch.float64), torch.randn(depth.shape, dtype=torch.float64)
+    torch.autograd.backward([points, depth], [gp.to(points), gd.to(depth)])
+    return idx, [a.grad for a in args], gp, gd
+  idx64, g64, gp, gd = run([t.double() for t in in32])
+  idx32, g32, _, _ = run(in32, gp, gd)
+  assert torch.equal(idx64, idx32)
+  idx = idx64.numpy()
+  v = len(idx)
+  pos, ls, rot, al, T, P = [npd(t) for t in in32]
+  sel = lambda a: np.ascontiguousarray(a[idx])
+  W, H = camera.image_size
+  d_pos = np.zeros((v, 3)); d_ls = np.zeros((v, 3)); d_rot = np.zeros((v, 4)); d_al = np.zeros(v); d_cam = np.zeros(16)
+  hostmath.hm_project_bwd_f32(dp(sel(pos)), dp(sel(ls)), dp(sel(rot)), dp(sel(al[:, 0])), dp(T), dp(P), int(W), int(H),
+                              ctypes.c_double(0.3), ctypes.c_double(0.15), ctypes.c_int64(v), dp(npd(gp)),
+                              dp(np.ascontiguousarray(npd(gd)[:, 0])), dp(d_pos), dp(d_ls), dp(d_rot), dp(d_al), dp(d_cam))
+  broke = False
+  for k, (name, got) in enumerate((('position', d_pos), ('log_scaling', d_ls), ('rotation', d_rot))):
+    want = g64[k].numpy()[idx]
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max(axis=1) / scale
+    ref = np.abs(g32[k].double().numpy()[idx] - want).max(axis=1) / scale
+    assert err.max() <= 1e-4, (name, err.max())
+    assert np.median(err) < 1e-6, (name, np.median(err))
+    broke = broke or ref.max() > 1e-3
+  assert broke, "the scene should contain rows on which the reference chain loses its digits in float32"
+
+
 @pytest.mark.parametrize('degree', range(4))
 def test_sh_forward_backward_vs_reference_fixture(hostmath, degree):
   fix = load_golden(f'sh_deg{degree}.pt')
