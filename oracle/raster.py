@@ -239,16 +239,20 @@ def gate_margin(points, ranges, o2p, image_size, cfg, tile_rows: Optional[Tuple[
   return margin
 
 
-def near_gate(points, ranges, o2p, image_size, cfg, eps: float):
+def near_gate(points, ranges, o2p, image_size, cfg, eps: float, return_counts: bool = False):
   """Where can a float32 implementation legitimately differ?  Returns (pixel_flag (H, W) bool: some (pixel, splat)
   pair of the pixel's tile list has alpha_pt * g within ``eps`` (relative) of the blend gate; splat_flag (V,) bool:
   the splat contributes — alpha above half the threshold — to such a pixel).  One flipped gate moves its pixel and,
   through T and the remaining colour, the gradient of EVERY splat that contributes to that pixel: tests on unfiltered
-  scenes require that each deviation beyond the tolerance is explained by these flags (and count the unexplained)."""
+  scenes require that each deviation beyond the tolerance is explained by these flags (and count the unexplained).
+  ``return_counts``: additionally (H, W) int — how many pairs of the pixel sit at the gate — which bounds how far the
+  pixel can move: one flipped pair of alpha ~ threshold at transmittance T changes the blended colour by
+  alpha T (-f + colour behind it / (T (1 - alpha))), at most 2 alpha_threshold max|f|."""
   w, h = image_size
   ts = cfg.tile_size
   tiles_wide, tiles_high = _tiles(image_size, ts)
   pixel_flag = torch.zeros((h, w), dtype=torch.bool)
+  pixel_count = torch.zeros((h, w), dtype=torch.int32)
   splat_flag = torch.zeros((points.shape[0],), dtype=torch.bool)
   ranges = ranges.reshape(-1, 2)
   for tile_id in range(tiles_wide * tiles_high):
@@ -261,10 +265,14 @@ def near_gate(points, ranges, o2p, image_size, cfg, eps: float):
     ids = o2p[start:end].long()
     g = points[ids]
     a_raw = g[None, :, 6] * pdf(pix[inb], g, cfg.antialias)                  # (pixels, splats)
-    flagged = ((a_raw / cfg.alpha_threshold - 1).abs() < eps).any(dim=1)
+    near = (a_raw / cfg.alpha_threshold - 1).abs() < eps
+    flagged = near.any(dim=1)
     pixel_flag[py[inb].long(), px[inb].long()] = flagged
+    pixel_count[py[inb].long(), px[inb].long()] = near.sum(dim=1).to(torch.int32)
     touched = ((a_raw > 0.5 * cfg.alpha_threshold) & flagged[:, None]).any(dim=0)
     splat_flag[ids[touched]] = True
+  if return_counts:
+    return pixel_flag, splat_flag, pixel_count
   return pixel_flag, splat_flag
 
 

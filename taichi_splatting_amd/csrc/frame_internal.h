@@ -83,6 +83,15 @@ int moments_finalize_rezero_launch(const float* points7, float* moments, int det
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
                                    hipStream_t s, int row_stride = 0);
 
+// ---- tools/experiments/raster_bwd_rows.hip (only with -DMS_WITH_ROWS_KERNEL, tools/build_variant.sh) ------------
+// the round-4 experiment (2x2 quad lists packed by DPP rows): tile 8 / 16; false = not served (tile 32, or
+// MS_RASTER_BWD=scan), the caller launches raster_bwd_scan_kernel
+struct FastParams;
+bool launch_rows_backward(const float* points7, const float* features, const int32_t* tile_ranges,
+                          const int32_t* overlap_to_point, const float* image, const float* grad_image,
+                          const FastParams& rp, int tile_size, bool heuristics, float* moments, const int32_t* fixed_exp,
+                          hipStream_t s);
+
 // ---- gaussian_bwd.hip -------------------------------------------------------------------------------------------
 // One pass over the gaussians for the whole per-gaussian backward of a frame: 2D-boundary gradients (from the raster
 // backward's moment rows, which it re-zeroes, or from gradient arrays) -> projection backward -> SH backward.

@@ -403,6 +403,7 @@ def check_replays(device=None, synchronize: bool = False):
     k = int(st.k_view[0])
     if k < 0 or k > st.capacity:
       st.overflowed = max(st.overflowed, k if k >= 0 else (1 << 31) - 1)
+      st.k_view[0] = 0             # taken note of; the next replay writes its own total
     if st.overflowed and (worst is None or st.overflowed > worst.overflowed):
       worst = st
   _captured_frames[:] = alive

@@ -18,10 +18,13 @@ from taichi_splatting_amd import RasterConfig, rasterize_with_tiles, map_to_tile
 from taichi_splatting_amd.perspective.projection import project_to_image
 from taichi_splatting_amd.rendering import ndc_depth
 from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+from .gate_excess import check_pixels, check_rows
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 GATE_EPS = 1e-5       # float32 evaluates alpha_pt * g to a few 1e-6 relative (v_exp_f32 of a 3-term fma chain)
+MAX_PIXELS_BEYOND = 5e-3    # share of the pixels allowed beyond 1e-4 (all of them explained and bounded; measured: see
+MAX_ROWS_BEYOND = 2e-2      # gpurun_out/parity_excess.jsonl / DESIGN.md section 5)
 
 
 @pytest.mark.parametrize('tile', [8, 16, 32])
@@ -50,23 +53,19 @@ def test_every_deviation_on_an_unfiltered_dense_scene_is_a_gate_flip(tile):
   ocfg = orast.Cfg(tile_size=tile)
   img_h, alpha_h, _ = orast.forward(p_h, f_h, ranges_h, o2p_h, size, ocfg)
   gp_h, gf_h, _ = orast.backward(p_h, f_h, ranges_h, o2p_h, img_h, G, size, ocfg)
-  pixel_flag, splat_flag = orast.near_gate(p_h, ranges_h, o2p_h, size, ocfg, GATE_EPS)
+  pixel_flag, splat_flag, pixel_count = orast.near_gate(p_h, ranges_h, o2p_h, size, ocfg, GATE_EPS, return_counts=True)
 
   per_tile = o2p.shape[0] / ranges[..., 0].numel()
   assert per_tile > 150 * (tile / 16) ** 2, per_tile                     # dense: hundreds of splats per tile
 
+  # unexplained deviations: none; explained ones: counted, capped, and no larger than their flipped gates allow
   err = (out.image.detach().cpu().double() - img_h).abs().max(-1).values
   err = torch.maximum(err, (out.image_weight.detach().cpu().double() - alpha_h).abs())
-  unexplained = (err > 1e-4) & ~pixel_flag
-  assert int(unexplained.sum()) == 0, (f"{int(unexplained.sum())} pixels differ from the oracle by more than 1e-4 without a pair "
-                                       f"within {GATE_EPS} of the gate (worst {float(err[unexplained].max()):.3e})")
+  check_pixels(err, pixel_flag, pixel_count, float(f_h.abs().max()), ocfg.alpha_threshold,
+               f"dense unfiltered scene, tile {tile}", max_fraction=MAX_PIXELS_BEYOND)
   assert float(err[~pixel_flag].max()) < 1e-4
-
   for name, got, want in (('gaussians2d', pg.grad, gp_h), ('features', fg.grad, gf_h)):
-    rel = ((got.cpu().double() - want).abs() / want.abs().max()).max(dim=1).values
-    bad = (rel > 1e-4) & ~splat_flag
-    assert int(bad.sum()) == 0, (f"d{name}: {int(bad.sum())} rows differ by more than 1e-4 of the largest gradient without a "
-                                 f"near-gate pixel under them (worst {float(rel[bad].max()):.3e})")
+    check_rows(got, want, splat_flag, f"dense unfiltered scene, tile {tile}, d{name}", max_fraction=MAX_ROWS_BEYOND)
   # the explanation is rare, not a blanket excuse: a small share of the pixels sits at the gate at all
   assert float(pixel_flag.float().mean()) < 0.05, float(pixel_flag.float().mean())
 

@@ -103,6 +103,16 @@ def main():
             f"chunks={chunks} fill={lanes / max(chunks, 1):.1f}/64 steps={steps} ({steps / max(chunks, 1):.1f}/chunk) "
             f"contributing pairs={pairs} ({pairs / max(steps, 1):.1f}/step)")
       print(f"stats: chunks of <= 16 splats {int(out[10])} ({int(out[10]) / max(chunks, 1):.3f}), of 17..32 splats {int(out[11])} ({int(out[11]) / max(chunks, 1):.3f})")
+      rows_fn = getattr(lib, 'ms_debug_rows_stats', None)      # raster_bwd_rows.hip (round 4) counts separately
+      if rows_fn is not None:
+        rows_fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        ro = (ctypes.c_ulonglong * 12)()
+        rows_fn(ctypes.cast(ro, ctypes.c_void_p), 1)
+        if ro[0]:
+          passes, hits, chunks, lanes, steps, pairs, phits = [int(v) for v in ro[:7]]
+          print(f"rows stats: passes={passes} (patch,splat) hits={phits} ({phits / o2p.shape[0]:.2f}/overlap) (quad,splat) hits={hits} "
+                f"({hits / o2p.shape[0]:.2f}/overlap) chunks={chunks} fill={lanes / max(chunks, 1):.1f}/64 pixel steps={steps} "
+                f"({steps / max(chunks, 1):.2f}/chunk) contributing pairs={pairs} ({pairs / max(steps, 1):.1f}/step)")
       if out[9]:
         print(f"stats: wave balance inside a workgroup: chunks run {int(out[8])}, slots until the batch barrier {int(out[9])} "
               f"-> {int(out[8]) / int(out[9]):.3f} of the barrier-to-barrier wave time is blend work")

@@ -14,6 +14,10 @@ for f in lib projection sh mapper scan_sort raster raster_fast raster_bwd_scan s
   /opt/rocm/bin/hipcc $flags "$@" -c "$src/$f.hip" -o "$out/$f.o" &
   pids+=($!)
 done
+case " $* " in *MS_WITH_ROWS_KERNEL*)      # the round-4 experiment, tools/experiments/raster_bwd_rows.hip
+  /opt/rocm/bin/hipcc $flags "$@" -I"$src" -c "$root/tools/experiments/raster_bwd_rows.hip" -o "$out/raster_bwd_rows.o" &
+  pids+=($!);;
+esac
 for p in "${pids[@]}"; do wait "$p"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/abl/lib$name.so" "$out"/*.o
 rm -rf "$out"
