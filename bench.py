@@ -10,7 +10,9 @@ already resident in HBM.  Default workload = BASELINE.json configs[3] ("config D
 
 N > 1: one rank per GPU over RCCL, either launched by ``torch.distributed.run`` (RANK / WORLD_SIZE in the
 environment) or, when ``--gpus N`` is given without that environment, by this script re-executing itself under
-``torch.distributed.run`` on 127.0.0.1.  The SAME frame is rendered by the N ranks ("scaling": "strong") in both
+``torch.distributed.run`` on 127.0.0.1.  The SAME frame is rendered by the N ranks ("scaling": "strong"), the camera
+moving through ``--views`` poses from step to step (per-view strip bounds and buffer capacities, probed outside the
+timed region as a trainer does once per view and epoch), in both
 decompositions, each timed for K steps with the sync-free rank steps of taichi_splatting_amd/sharded.py
 (``--legacy-steps``: the round-2 steps of distributed.py): ``strips`` (north_star: gaussians replicated, tile-row
 strips, reduce-scatter + all-gather of the 2D-boundary gradients) and ``sharded`` (gaussians sharded by index,
@@ -70,6 +72,10 @@ def parse_args():
                       'total) instead of the sync-free steps of sharded.py')
   p.add_argument('--rank-graph', action='store_true',
                  help='N > 1: replay the rank step from a HIP graph (RCCL collectives captured with it); off by default')
+  p.add_argument('--views', type=int, default=4,
+                 help='N > 1: number of camera poses the timed loop cycles through (a trainer visits a different view '
+                      'every step).  Strip bounds and buffer capacities are per view, probed once per view outside the '
+                      'timed region — the per-epoch cost a trainer amortises over its views; 1 = one static camera')
   p.add_argument('--launcher', action='store_true',
                  help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
   return p.parse_args()
@@ -180,8 +186,10 @@ def stage_breakdown(g, cam, cfg, use_sh):
 
 def cpu_baseline(args):
   """The CPU oracle (torch restatement of the reference path; the reference has no CPU rasterizer)
-  timed on a bounded sample of the same workload family at config D's density
-  (1.43 gaussians per pixel): 300k gaussians, 888x888, fwd+bwd (10-20 s of CPU work on 8 threads)."""
+  timed on a bounded sample of the same workload family (the bench scene's generator):
+  300k gaussians, 888x888, SH degree 3, fwd+bwd — 0.38 gaussians per pixel with 3.2 overlaps each (config D: 1.43 per
+  pixel, 2.1 overlaps each; at config D's density the sample would take ~100 s) — 15-25 s of CPU work on 8 threads;
+  plus BASELINE configs[0] in full (``config_a``)."""
   import numpy as np
   from oracle import mapper as omap, projection as oproj, raster as orast, sh as osh
   from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
@@ -215,9 +223,41 @@ def cpu_baseline(args):
   gp, gf, _ = orast.backward(points.detach(), feats.detach(), ranges, o2p, image, torch.ones_like(image), size, cfg)
   torch.autograd.backward([points, feats], [gp, gf])
   dt = time.perf_counter() - t0
+
+  # BASELINE.json configs[0] in full: 10k random 2D gaussians, 256x256, forward only — the reference's own
+  # CPU-runnable case, mapper + raster forward of the oracle
+  from taichi_splatting_amd.testing import random_2d_gaussians
+  from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+  torch.manual_seed(0)
+  g2 = random_2d_gaussians(10_000, (256, 256))
+  ta = time.perf_counter()
+  p2 = project_gaussians2d(g2)
+  o2p_a, ranges_a, _ = omap.map_to_tiles(p2.numpy(), g2.depths.numpy(), (256, 256), cfg.tile_size, cfg.alpha_threshold)
+  orast.forward(p2, g2.feature, torch.from_numpy(ranges_a), torch.from_numpy(o2p_a), (256, 256), cfg)
+  dta = time.perf_counter() - ta
   return {"value": round(n / dt / 1e6, 5), "unit": "Msplats/s", "cores": torch.get_num_threads(), "kind": "port",
           "sample": f"oracle (torch {torch.__version__} CPU restatement) fwd+bwd, {n} gaussians, {size[0]}x{size[1]}, "
-                    f"SH deg {args.sh_degree}, tile {args.tile}, K={int(o2p.shape[0])}, {dt:.2f} s"}
+                    f"SH deg {args.sh_degree}, tile {args.tile}, K={int(o2p.shape[0])}, {dt:.2f} s",
+          "config_a": {"value": round(10_000 / dta / 1e6, 5), "unit": "Msplats/s",
+                       "sample": f"BASELINE configs[0] in full: 10000 random 2D gaussians, 256x256, forward only (oracle mapper + "
+                                 f"raster forward), K={int(o2p_a.shape[0])}, {dta:.2f} s"}}
+
+
+def view_camera(cam, v):
+  """Camera pose number v of the N > 1 benchmark loop: the scene's camera rolled by 0.04 v rad about its optical axis
+  and shifted sideways by 0.03 v scene units — the same gaussians stay in view, but which tile rows they fall into,
+  hence the strips' work and every rank's buckets, changes from step to step.  Deterministic: all ranks agree."""
+  if v == 0:
+    return cam
+  import math
+  T = cam.T_camera_world.clone()
+  c, s_ = math.cos(0.04 * v), math.sin(0.04 * v)
+  roll = torch.eye(4, dtype=T.dtype, device=T.device)
+  roll[0, 0], roll[0, 1], roll[1, 0], roll[1, 1] = c, -s_, s_, c
+  T = roll @ T.reshape(4, 4)
+  T[0, 3] += 0.03 * v
+  return cam.__class__(projection=cam.projection, T_camera_world=T, near_plane=cam.near_plane, far_plane=cam.far_plane,
+                       image_size=cam.image_size)
 
 
 def log(msg):
@@ -256,16 +296,22 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
 
   g = scene
   shard_begin = 0
-  bounds = None
-  if world > 1 and not args.even_strips:
-    # strips cut where the per-tile-row overlap histogram says, once for this (static) scene and camera, outside
-    # the timed region: the gaussians' projection is replicated work here, one small all-reduce for sharded input
+  use_static = mode in ('sharded', 'strips') and not args.legacy_steps
+  n_views = max(1, args.views) if use_static else 1      # also at world size 1 (--launcher --mode ...): same code path
+  cams = [view_camera(cam, v) for v in range(n_views)]
+
+  def balanced_bounds(camera):
+    # strips cut where the per-tile-row overlap histogram says, per VIEW, outside the timed region (a trainer does this
+    # once per view and epoch): the gaussians' projection is replicated work here, one small all-reduce for sharded input
     from taichi_splatting_amd.distributed import overlap_balanced_bounds
     from taichi_splatting_amd.perspective.projection import project_to_image
     with torch.no_grad():
       part = scene if mode == 'strips' else scene[slice(*shard_range(args.n, world, rank))]
-      bounds = overlap_balanced_bounds(project_to_image(part, cam, cfg)[0], cam.image_size, cfg, world,
-                                       all_reduce=(mode == 'sharded'))
+      return overlap_balanced_bounds(project_to_image(part, camera, cfg)[0], camera.image_size, cfg, world,
+                                     all_reduce=(mode == 'sharded'))
+  bounds = None
+  if world > 1 and not args.even_strips:
+    bounds = balanced_bounds(cam)
     log(f"[{mode}] tile-row bounds {bounds}")
   if mode == 'sharded':
     # every rank generated the same scene (same seed); it keeps only its shard of the gaussians
@@ -275,29 +321,43 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
   leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
   comm = {}
 
-  static = None
-  if mode in ('sharded', 'strips') and not args.legacy_steps:
-    # sync-free rank steps (taichi_splatting_amd/sharded.py): capacities from one synchronising dry run, here, outside
-    # the timed region (like the strip bounds)
+  static, statics = None, []
+  if use_static:
+    # sync-free rank steps (taichi_splatting_amd/sharded.py), one per view: capacities from one synchronising dry run
+    # per view, here, outside the timed region (like the strip bounds)
     from taichi_splatting_amd import sharded
     from taichi_splatting_amd.distributed import strip_bounds
     ts = cfg.tile_size
     tiles_high = (cam.image_size[1] + ts - 1) // ts
-    use_bounds = bounds if bounds is not None else strip_bounds(tiles_high, world)
     cls = sharded.ShardedStep if mode == 'sharded' else sharded.StripStep
     kw = dict(index_offset=shard_begin) if mode == 'sharded' else {}
-    static = cls(cam.image_size, cfg, cam.depth_range, rank, world, use_bounds, **kw)
-    with torch.no_grad():
-      caps = static.probe(g, cam, True)
-    log(f"[{mode}] sync-free step, capacities {caps}")
+    for v, camera in enumerate(cams):
+      b = bounds if v == 0 else (balanced_bounds(camera) if (world > 1 and not args.even_strips) else None)
+      use_bounds = b if b is not None else strip_bounds(tiles_high, world)
+      st = cls(camera.image_size, cfg, camera.depth_range, rank, world, use_bounds, **kw)
+      with torch.no_grad():
+        caps = st.probe(g, camera, True)
+      statics.append(st)
+      log(f"[{mode}] view {v}: sync-free step, bounds {use_bounds}, capacities {caps}")
+    static = statics[0]
+    comm['views'] = n_views
   loss_fn = lambda img, rows: img.sum()
 
-  def step():
+  counter = [0]
+
+  def step_view(v):
     for t in leaves:
       t.grad = None
+    statics[v].step(g, cams[v], loss_fn, use_sh=True, backward=not args.forward_only)
+
+  def step():
     if static is not None:
-      static.step(g, cam, loss_fn, use_sh=True, backward=not args.forward_only)
-    elif mode == 'sharded':
+      v = counter[0] % n_views          # a different camera pose every step
+      counter[0] += 1
+      return step_view(v)
+    for t in leaves:
+      t.grad = None
+    if mode == 'sharded':
       render_sharded_step(g, cam, cfg, lambda img, rows: img.sum(), use_sh=True, rank=rank, world_size=world,
                           backward=not args.forward_only, index_offset=shard_begin, comm_stats=comm, bounds=bounds)
     elif mode == 'strips':
@@ -333,8 +393,13 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
   run = step
   if static is not None and args.rank_graph:
     from taichi_splatting_amd import frame as frame_mod0
-    graph = frame_mod0.FrameGraph(step, warmup=1)
-    run = graph.replay
+    # one captured step per view, replayed round robin
+    graphs = [frame_mod0.FrameGraph(lambda v=v: step_view(v), warmup=1) for v in range(n_views)]
+    counter[0] = 0
+
+    def run():
+      graphs[counter[0] % n_views].replay()
+      counter[0] += 1
     comm['hip_graph'] = True
 
   from taichi_splatting_amd import frame as frame_mod
@@ -359,16 +424,21 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
     # and the overflow flags of the fixed-capacity buffers
     from taichi_splatting_amd import sharded
     comm.update(static.comm_bytes)
-    status = static.check()
-    if status.get('overlap_overflow') or status.get('bucket_overflow'):
-      raise RuntimeError(f"[{mode}] rank {rank}: a fixed-capacity buffer overflowed ({status}); the timed frames are invalid")
-    static.timer = sharded.StageTimer(True)
-    for _ in range(5):
+    for v, st in enumerate(statics):
+      st.poll()                          # raises FrameOverflow if a timed step of this view overflowed a capacity
+      status = st.check()
+      if status.get('overlap_overflow') or status.get('bucket_overflow'):
+        raise RuntimeError(f"[{mode}] rank {rank}, view {v}: a fixed-capacity buffer overflowed ({status}); the timed frames are invalid")
+    timer = sharded.StageTimer(True)
+    for st in statics:
+      st.timer = timer
+    for _ in range(max(5, n_views)):
       step()
       torch.cuda.synchronize()
-      static.timer.end_step()
-    comm['stage_ms'] = static.timer.mean_ms()
-    static.timer = sharded.StageTimer(False)
+      timer.end_step()
+    comm['stage_ms'] = timer.mean_ms()
+    for st in statics:
+      st.timer = sharded.StageTimer(False)
     barrier()
   per_rank = [mine]
   if distributed:

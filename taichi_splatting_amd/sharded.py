@@ -240,6 +240,17 @@ class StripStep(_RankStep):
   gradients.  ``step(gaussians, camera, loss_fn)``: ``loss_fn(strip_image, (y0, y1))`` gets ONLY the strip's pixel
   rows; afterwards ``.grad`` of the gaussians' leaf tensors holds the full gradient (identical on every rank)."""
 
+  def __init__(self, *args, reduce=None, **kw):
+    super().__init__(*args, **kw)
+    # reduce(buf (rows, 7 + f), shard (rows / world, 7 + f)): sum over the ranks, result back in every rank's buf.
+    # Default: ONE reduce-scatter + ONE all-gather (RCCL).  tools/emulate_sharded.py substitutes device copies of the
+    # same buffers to time a rank's own work on one GPU.
+    self.reduce = reduce or self._reduce_scatter_all_gather
+
+  def _reduce_scatter_all_gather(self, buf, shard):
+    dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
+    dist.all_gather_into_tensor(buf, shard, group=self.group)
+
   def probe(self, gaussians: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.15):
     """one synchronising dry run: fixes the overlap-list capacity of this rank's strip"""
     from .mapper.tile_mapper import map_to_tiles_strip
@@ -312,8 +323,7 @@ class StripStep(_RankStep):
         buf[:n, :7] = gp
         buf[:n, 7:] = gc
       shard = torch.empty((rows // self.world, width), dtype=dtype, device=device)
-      dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
-      dist.all_gather_into_tensor(buf, shard, group=self.group)
+      self.reduce(buf, shard)
       if not in_place:
         gp, gc = buf[:n, :7].contiguous(), buf[:n, 7:].contiguous()
       self.comm_bytes = {"reduce_scatter_plus_all_gather_buffer_bytes": rows * width * buf.element_size()}

@@ -10,11 +10,10 @@ Each configuration is checked twice:
     BASELINE.json's north_star with the float64 oracle rasterizer evaluated on the SAME float32 splats the kernels
     rasterized (the rasterizer is judged on its inputs), and every pixel to 2e-4 with the all-float64 oracle
     pipeline (the float32 projection perturbs the splat parameters by ~1e-6, a near-isotropic splat's axis by more).
-    The gradients of the 3D parameters go through the projection backward, whose float32 evaluation is
-    ill-conditioned for some gaussians in ANY implementation of the reference's formulas (eigen-decomposition of
-    a near-isotropic blurred covariance, quaternion normalisation): torch_lib's own arithmetic run in float32 is
-    off by 1e-3 ... 1e+3 times the largest gradient on such rows.  They are held to 1e-4 on >= 99 % of the
-    gaussians and everywhere to the accuracy of the oracle evaluated in float32
+    The gradients of the 3D parameters go through the projection backward.  The reference's formula chain is
+    ill-conditioned in float32 for nearly isotropic blurred covariances (torch_lib's own arithmetic run in float32
+    is off by 1e-3 ... 1e+3 times the largest gradient on such rows); since round 4 the kernels evaluate the
+    eigen-pair derivative in closed form and are held to 1e-4 on >= 99.9 % of the gaussians, none beyond 1e-3
     (tests/test_gpu_projection_sh.py::assert_f32_gradient_as_accurate_as_reference states the criterion);
   * at full size through size-independent properties: mapper invariants, the float32 product kernels against
     the float64 generic kernels on the same tile lists, tile-row strips composing to the full frame in image and
@@ -29,10 +28,13 @@ from taichi_splatting_amd.perspective.projection import project_to_image
 from taichi_splatting_amd.rendering import ndc_depth
 from taichi_splatting_amd.spherical_harmonics import evaluate_sh_at
 from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+from .gate_excess import check_pixels, check_rows
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 LEAVES = ('position', 'log_scaling', 'rotation', 'alpha_logit', 'feature')
+MAX_PIXELS_BEYOND = 5e-3    # share of pixels / gradient rows allowed beyond 1e-4 on unfiltered full-size scenes: all of
+MAX_ROWS_BEYOND = 2e-2      # them explained by a near-gate pair AND bounded (tests/gate_excess.py)
 
 
 def scene(n, size, seed=0, sh_degree=3):
@@ -143,10 +145,13 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   for k, got, w in (('gaussians2d', r.points.gaussians2d.grad, gp_h), ('features', r.points.features.grad, gf_h)):
     scale = w.abs().max().item()
     assert (got.cpu().double() - w).abs().max() < 1e-4 * scale, (name, k, (got.cpu().double() - w).abs().max().item(), scale)
-  # 3D parameters: the projection / SH backward stage, fed with the kernels' own 2D-boundary gradients in all
-  # three evaluations (kernels, float64 oracle chain, float32 oracle chain); see the module docstring
+  # 3D parameters.  Truth = the float64 oracle rasterizer's 2D-boundary gradients (on the kernels' own splats) through
+  # the float64 projection / SH chain.  The fused per-gaussian pass does not go through (d axis, d sigma) at all — it
+  # hands the projection backward the covariance gradient formed from the moment sums (csrc/gaussian_bwd.hip) — so it
+  # is compared with the exact chain, not with a chain fed by its own float32 2D gradients.  ref32 = what the
+  # reference's arithmetic yields at the product's precision, fed with the kernels' float32 2D gradients.
   gp_k, gf_k = r.points.gaussians2d.grad.cpu().double(), r.points.features.grad.cpu().double()
-  idx64, ref64 = oracle_leaf_grads(g, cam, cfg, gp_k, gf_k, torch.float64)
+  idx64, ref64 = oracle_leaf_grads(g, cam, cfg, gp_h, gf_h, torch.float64)
   idx32, ref32 = oracle_leaf_grads(g, cam, cfg, gp_k, gf_k, torch.float32)
   assert torch.equal(idx32, want['idx']) and torch.equal(idx64, want['idx'])
   from .test_gpu_projection_sh import assert_f32_gradient_as_accurate_as_reference
@@ -224,7 +229,7 @@ def strips_compose(g, cam, cfg, bounds, full_image, full_grads):
     assert (got - want).abs().max() < 1e-4 * scale, (k, (got - want).abs().max().item(), scale)
 
 
-def near_gate_gpu(points, o2p, ranges, image_size, cfg, eps, chunk=1 << 20):
+def near_gate_gpu(points, o2p, ranges, image_size, cfg, eps, chunk=1 << 20, return_counts=False):
   """oracle.raster.near_gate at full size, vectorised on the GPU in float64: (pixel_flag (H, W), splat_flag (V,)).
   Every (tile, splat) overlap is expanded to the tile's ts x ts pixels, a chunk of overlaps at a time."""
   w, h = image_size
@@ -256,15 +261,19 @@ def near_gate_gpu(points, o2p, ranges, image_size, cfg, eps, chunk=1 << 20):
     inb = (px < w) & (py < h)
     return ids, a, (py.long().clamp(max=h - 1) * w + px.long().clamp(max=w - 1)), inb
   pixel_flag = torch.zeros((h * w,), dtype=torch.bool, device=dev)
+  pixel_count = torch.zeros((h * w,), dtype=torch.int32, device=dev)        # pairs at the gate per pixel
   for k0 in range(0, o2p.shape[0], chunk):
     ids, a, lin, inb = a_raw_of(k0, min(k0 + chunk, o2p.shape[0]))
     near = ((a / cfg.alpha_threshold - 1).abs() < eps) & inb
     pixel_flag[lin[near]] = True
+    pixel_count.index_add_(0, lin[near], torch.ones_like(lin[near], dtype=torch.int32))
   splat_flag = torch.zeros((points.shape[0],), dtype=torch.bool, device=dev)
   for k0 in range(0, o2p.shape[0], chunk):
     ids, a, lin, inb = a_raw_of(k0, min(k0 + chunk, o2p.shape[0]))
     touched = ((a > 0.5 * cfg.alpha_threshold) & inb & pixel_flag[lin]).any(dim=1)
     splat_flag[ids[touched]] = True
+  if return_counts:
+    return pixel_flag.view(h, w), splat_flag, pixel_count.view(h, w)
   return pixel_flag.view(h, w), splat_flag
 
 
@@ -301,15 +310,14 @@ def test_config_c_full_size():
     res[dtype] = (out.image.detach().double(), pp.grad.double(), ff.grad.double())
   # nothing is filtered and nothing is a quantile: every pixel / 2D-gradient row beyond 1e-4 must be explained by a
   # (pixel, splat) pair within 1e-5 of the blend gate (near_gate_gpu = oracle.raster.near_gate at full size)
-  pixel_flag, splat_flag = near_gate_gpu(p, o2p, ranges, cam.image_size, cfg, 1e-5)
+  pixel_flag, splat_flag, pixel_count = near_gate_gpu(p, o2p, ranges, cam.image_size, cfg, 1e-5, return_counts=True)
   err = (res[torch.float32][0] - res[torch.float64][0]).abs().max(-1).values
-  unexplained = (err > 1e-4) & ~pixel_flag
-  assert int(unexplained.sum()) == 0, (int(unexplained.sum()), float(err[unexplained].max()))
+  # unexplained: none; explained: counted, capped and no larger than the flagged pairs allow (tests/gate_excess.py)
+  check_pixels(err, pixel_flag, pixel_count, float(feats.abs().max()), cfg.alpha_threshold, "config C full size",
+               max_fraction=MAX_PIXELS_BEYOND)
   assert float(pixel_flag.float().mean()) < 0.05
-  for got, want in zip(res[torch.float32][1:], res[torch.float64][1:]):
-    rel = ((got - want).abs() / want.abs().max()).max(dim=1).values
-    bad = (rel > 1e-4) & ~splat_flag
-    assert int(bad.sum()) == 0, (int(bad.sum()), float(rel[bad].max()))
+  for name, got, want in zip(('gaussians2d', 'features'), res[torch.float32][1:], res[torch.float64][1:]):
+    check_rows(got, want, splat_flag, f"config C full size, d{name}", max_fraction=MAX_ROWS_BEYOND)
 
   r, grads = full_frame(g, cam, cfg)
   assert r.image.shape == (1080, 1920, 3) and float(r.image.detach().min()) >= 0
@@ -336,15 +344,14 @@ def test_config_d_full_size_every_deviation_explained(tile):
     out = rasterize_with_tiles(pp, ff, o2p, ranges.view(-1, 2), cam.image_size, cfg)
     (out.image * G.to(dtype)).sum().backward()
     res[dtype] = (out.image.detach().double(), pp.grad.double(), ff.grad.double())
-  pixel_flag, splat_flag = near_gate_gpu(p, o2p, ranges, cam.image_size, cfg, 1e-5, chunk=(1 << 28) // (tile * tile))
+  pixel_flag, splat_flag, pixel_count = near_gate_gpu(p, o2p, ranges, cam.image_size, cfg, 1e-5,
+                                                      chunk=(1 << 28) // (tile * tile), return_counts=True)
   err = (res[torch.float32][0] - res[torch.float64][0]).abs().max(-1).values
-  unexplained = (err > 1e-4) & ~pixel_flag
-  assert int(unexplained.sum()) == 0, (int(unexplained.sum()), float(err[unexplained].max()))
+  check_pixels(err, pixel_flag, pixel_count, float(feats.abs().max()), cfg.alpha_threshold,
+               f"config D full size, tile {tile}", max_fraction=MAX_PIXELS_BEYOND)
   assert float(pixel_flag.float().mean()) < 0.05
-  for got, want in zip(res[torch.float32][1:], res[torch.float64][1:]):
-    rel = ((got - want).abs() / want.abs().max()).max(dim=1).values
-    bad = (rel > 1e-4) & ~splat_flag
-    assert int(bad.sum()) == 0, (int(bad.sum()), float(rel[bad].max()))
+  for name, got, want in zip(('gaussians2d', 'features'), res[torch.float32][1:], res[torch.float64][1:]):
+    check_rows(got, want, splat_flag, f"config D full size, tile {tile}, d{name}", max_fraction=MAX_ROWS_BEYOND)
 
 
 @pytest.mark.parametrize('tile', [16, 32])

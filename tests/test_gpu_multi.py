@@ -38,6 +38,8 @@ def test_rank_steps_on_one_rank_report_stages(extra):
   assert out['config']['mode'] == 'sharded' and out['value'] > 0
   if '--legacy-steps' not in extra:
     assert out['host_syncs_per_step'] == 0
+    # the timed loop moves the camera: four poses, each with its own bounds / capacities (probed outside the loop)
+    assert out['modes']['sharded']['rank0_step']['views'] == 4
 
 
 @pytest.mark.gpu

@@ -72,7 +72,7 @@ def test_projection_fixture_f64(seed):
     assert torch.allclose(g.cpu(), gr, rtol=1e-5, atol=1e-9), (name, (g.cpu() - gr).abs().max())
 
 
-@pytest.mark.parametrize('seed', range(20))
+@pytest.mark.parametrize('seed', range(100))         # the reference's count (tests/test_projection.py:76,100)
 def test_projection_random_vs_oracle(seed):
   # protocol of tests/test_projection.py:22-96 (random camera, 1..10000 points, margin .5)
   torch.manual_seed(seed)
@@ -175,7 +175,7 @@ def test_sh_fixture_f64(degree):
     assert torch.allclose(g.cpu(), gr, atol=1e-10), (g.cpu() - gr).abs().max()
 
 
-@pytest.mark.parametrize('seed', range(30))
+@pytest.mark.parametrize('seed', range(100))         # the reference's count (tests/test_spherical_harmonics.py:33,52)
 def test_sh_random_f32_vs_oracle(seed):
   # protocol of tests/test_spherical_harmonics.py:16-45 (f32, atol 1e-5, repeated indexes)
   torch.random.manual_seed(seed)

@@ -71,7 +71,13 @@ def main():
   p.add_argument('--static', action='store_true',
                  help='the sync-free step of taichi_splatting_amd/sharded.py (ShardedStep: fixed buckets, frame executor), '
                       'timed eagerly and as a HIP-graph replay')
+  p.add_argument('--strips', action='store_true',
+                 help='the north_star partition (sharded.StripStep: replicated gaussians, tile-row strips, reduce-scatter + '
+                      'all-gather of the 2D-boundary gradients), the collective replaced by device copies of its buffers')
+  p.add_argument('--out', type=str, default='', help='also write the JSON line to this file (profiles/emul_*.json)')
   args = p.parse_args()
+  if args.strips:
+    return main_strips(args)
   if args.static:
     return main_static(args)
   import bench
@@ -142,7 +148,93 @@ def main():
          "per_rank_ms": per_rank, "max_rank_ms": max(per_rank), "recv_splats": recv,
          "compute_only_speedup": round(t_single / max(per_rank), 2),
          "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
-  print(json.dumps(out))
+  emit(args, out)
+
+
+def emit(args, out):
+  line = json.dumps(out)
+  print(line)
+  if args.out:
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+    with open(args.out, 'w') as f:
+      f.write(line + '\n')
+
+
+def main_strips(args):
+  """StripStep per rank on one GPU.  Every rank holds all gaussians; rank r renders strip r.  The reduce-scatter +
+  all-gather of the (rows, 7 + f) gradient buffer is replaced by what it costs the GPU itself: the rank's own piece
+  copied out and W pieces written back into the buffer (the sum over ranks and the xGMI transfers are what is NOT
+  measured: 2 x (W - 1) / W x 40 B x N per rank over the links)."""
+  import bench
+  from taichi_splatting_amd import RasterConfig, frame, render_gaussians, sharded
+  from taichi_splatting_amd.distributed import overlap_balanced_bounds
+  from taichi_splatting_amd.perspective.projection import project_to_image
+  dev = torch.device('cuda', 0)
+  cfg = RasterConfig(tile_size=args.tile, pixel_stride=(1, 1) if args.tile == 8 else (2, 2))
+  g, cam = bench.make_scene(args, dev)
+  W = args.world
+  size = cam.image_size
+  loss_fn = lambda img, rows: img.sum()
+
+  def timed(fn, steps=None):
+    steps = steps or max(args.steps, 20)
+    for _ in range(max(args.warmup, 10)):
+      fn()
+    torch.cuda.synchronize()
+    with frame.parked_gc():
+      t0 = time.perf_counter()
+      for _ in range(steps):
+        fn()
+      torch.cuda.synchronize()
+      return (time.perf_counter() - t0) / steps * 1e3
+
+  full = g.clone().requires_grad_(True)
+  leaves = (full.position, full.log_scaling, full.rotation, full.alpha_logit, full.feature)
+
+  def single():
+    for t in leaves:
+      t.grad = None
+    render_gaussians(full, cam, cfg, use_sh=True).image.sum().backward()
+  t_single = timed(single)
+  with torch.no_grad():
+    bounds = overlap_balanced_bounds(project_to_image(g, cam, cfg)[0], size, cfg, W)
+
+  per_rank, per_rank_graph, stages = [], [], []
+  for r in ([int(x) for x in args.ranks.split(',')] if args.ranks else range(W)):
+    def fake_reduce(buf, shard, r=r):
+      piece = shard.shape[0]
+      shard.copy_(buf[r * piece:(r + 1) * piece])            # my piece of the reduce-scatter
+      buf.view(W, piece, -1).copy_(shard.unsqueeze(0).expand(W, -1, -1))     # the all-gather writes W pieces
+    st = sharded.StripStep(size, cfg, cam.depth_range, r, W, bounds, reduce=fake_reduce)
+    st.probe(full, cam, True)
+
+    def step():
+      for t in leaves:
+        t.grad = None
+      st.step(full, cam, loss_fn, use_sh=True)
+    per_rank.append(round(timed(step), 3))
+    st.timer = sharded.StageTimer(True)
+    for _ in range(5):
+      step(); torch.cuda.synchronize(); st.timer.end_step()
+    stages.append(st.timer.mean_ms())
+    st.timer = sharded.StageTimer(False)
+    graph = frame.FrameGraph(step, warmup=1)
+    per_rank_graph.append(round(timed(graph.replay), 3))
+    assert not st.check()['overlap_overflow']
+    del graph
+  es = 4
+  rows = (args.n + W - 1) // W * W
+  out = {"world": W, "n": args.n, "image": list(size), "step": "sharded.StripStep (north_star: replicated gaussians, strips, "
+         "reduce-scatter + all-gather)", "single_gpu_ms": round(t_single, 3), "bounds": bounds,
+         "per_rank_ms_eager": per_rank, "per_rank_ms_graph": per_rank_graph,
+         "max_rank_ms_eager": max(per_rank), "max_rank_ms_graph": max(per_rank_graph),
+         "compute_only_speedup_eager": round(t_single / max(per_rank), 2),
+         "compute_only_speedup_graph": round(t_single / max(per_rank_graph), 2),
+         "stage_ms_rank0": stages[0],
+         "collective_bytes_per_rank": {"buffer": rows * 10 * es, "sent_over_xgmi": int(2 * (W - 1) / W * rows * 10 * es)},
+         "note": "the cross-rank sum and the xGMI transfers of the reduce-scatter + all-gather are NOT included (device "
+                 "copies of the same buffers stand in)"}
+  emit(args, out)
 
 
 def main_static(args):
@@ -256,7 +348,7 @@ def main_static(args):
          "compute_only_speedup_graph": round(t_single / max(per_rank_graph), 2),
          "stage_ms_rank0": stages[0],
          "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
-  print(json.dumps(out))
+  emit(args, out)
 
 
 if __name__ == '__main__':
