@@ -319,7 +319,19 @@ typedef struct ms_frame_grads {
   const void* gather_rows;
   const int32_t* gather_slots;     /* out_slots of ms_strip_route_pack_slots */
   const int32_t* gather_route;     /* out_route of ms_strip_route_count */
+  int32_t boundary_form;           /* form of the 2D-boundary gradient rows that MS_BACKWARD_RASTER stores (moments path) and
+                                      MS_BACKWARD_GAUSSIANS reads.  0 = MS_BOUNDARY_AXIS_SIGMA: d(packed 2D gaussian) as the
+                                      reference's rasterizer returns it, [d mean (2) | d axis (2) | d sigma (2) | d alpha].
+                                      1 = MS_BOUNDARY_COVARIANCE: [d mean (2) | dL/d(a, b, c) of the 2D covariance
+                                      [[a, b], [b, c]] (3) | 0 | d alpha] — the same 7 columns.  The plain gaussian pdf depends
+                                      on (axis, sigma) only through the covariance; handed over in this form the gradient
+                                      never passes through the derivative of the eigen-decomposition (no division by
+                                      l1 - l2: float32 rows of nearly isotropic splats keep their digits), and rows of
+                                      one gaussian from several strips / ranks simply add.  Multi-GPU rank steps use 1. */
+  int32_t reserved0;
 } ms_frame_grads;
+
+enum { MS_BOUNDARY_AXIS_SIGMA = 0, MS_BOUNDARY_COVARIANCE = 1 };
 
 int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
 int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic);

@@ -19,9 +19,12 @@ def quat_to_mat(q: torch.Tensor) -> torch.Tensor:
   return torch.stack(rows, dim=-1).reshape(q.shape[:-1] + (3, 3))
 
 
-def project_all(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
-                image_size, depth_range, blur_cov=0.0, clamp_margin=0.15, alpha_threshold=1. / 255.):
-  """Projects every gaussian; returns (points (N,7), depth (N,), in_view (N,) bool)."""
+def covariance_all(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
+                   image_size, blur_cov=0.0, clamp_margin=0.15):
+  """The projection up to the blurred 2D covariance: (uv (N, 2), a, b, c (N,), alpha (N,), z (N,)) with
+  covariance [[a, b], [b, c]] — everything ``project_all`` computes before the eigen-decomposition.  Tests use it to
+  push a covariance gradient through the float64 chain (the rasterizer's gradient does not depend on how the
+  covariance is factored into axis and sigma)."""
   dtype, device = position.dtype, position.device
   W, H = image_size
   size = torch.tensor([W, H], dtype=dtype, device=device)
@@ -46,6 +49,18 @@ def project_all(position, log_scaling, rotation, alpha_logit, T_camera_world, pr
   a = cov[:, 0, 0] + blur_cov
   b = cov[:, 0, 1]
   cc = cov[:, 1, 1] + blur_cov
+  alpha = 1.0 / (1.0 + torch.exp(-alpha_logit.reshape(-1)))
+  return uv, a, b, cc, alpha, z
+
+
+def project_all(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
+                image_size, depth_range, blur_cov=0.0, clamp_margin=0.15, alpha_threshold=1. / 255.):
+  """Projects every gaussian; returns (points (N,7), depth (N,), in_view (N,) bool)."""
+  dtype, device = position.dtype, position.device
+  W, H = image_size
+  size = torch.tensor([W, H], dtype=dtype, device=device)
+  uv, a, b, cc, alpha, z = covariance_all(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
+                                          image_size, blur_cov, clamp_margin)
 
   # eig (generic.py:217-230)
   tr = a + cc
@@ -58,7 +73,6 @@ def project_all(position, log_scaling, rotation, alpha_logit, T_camera_world, pr
   v1 = v / torch.sqrt((v * v).sum(-1, keepdim=True))
   v2 = torch.stack([-v1[:, 1], v1[:, 0]], dim=-1)
 
-  alpha = 1.0 / (1.0 + torch.exp(-alpha_logit.reshape(-1)))
   gs = torch.sqrt(2 * torch.log(alpha / alpha_threshold))   # NaN when alpha < threshold => culled
   sc = sigma * gs.unsqueeze(1)
   e1, e2 = v1 * sc[:, 0:1], v2 * sc[:, 1:2]

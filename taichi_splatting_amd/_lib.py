@@ -21,6 +21,7 @@ LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB') or PACKAGE_DIR / 'libmi355_splat.
 
 MS_F32, MS_F64 = 0, 1
 BACKWARD_ALL, BACKWARD_GAUSSIANS, BACKWARD_RASTER = 0, 1, 2   # ms_frame_grads.stage
+BOUNDARY_AXIS_SIGMA, BOUNDARY_COVARIANCE = 0, 1               # ms_frame_grads.boundary_form
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
 
 _lib: Optional[ctypes.CDLL] = None
@@ -83,6 +84,7 @@ class FrameGradsC(ctypes.Structure):
     ('point_heuristic', c_void_p),
     ('boundary_stride', c_int32), ('gather_world', c_int32),
     ('gather_rows', c_void_p), ('gather_slots', c_void_p), ('gather_route', c_void_p),
+    ('boundary_form', c_int32), ('reserved0', c_int32),
   ]
 
 

@@ -317,6 +317,9 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   const bool given = gr->stage == MS_BACKWARD_GAUSSIANS;
   const bool raster_only = gr->stage == MS_BACKWARD_RASTER || d.projected_input;
   const bool moments = !given && frame_uses_moments(desc, gr->deterministic);
+  MS_CHECK_ARG(gr->boundary_form == MS_BOUNDARY_AXIS_SIGMA || gr->boundary_form == MS_BOUNDARY_COVARIANCE, "boundary_form");
+  MS_CHECK_ARG(gr->boundary_form == 0 || given || (moments && gr->stage == MS_BACKWARD_RASTER),
+               "MS_BOUNDARY_COVARIANCE rows: MS_BACKWARD_GAUSSIANS, or MS_BACKWARD_RASTER on the moments path");
   if (gr->boundary_stride != 0) {
     MS_CHECK_ARG(gr->boundary_stride >= 7 + d.f && d.dtype == MS_F32, "boundary_stride: rows of >= 7 + f floats, float32 frames");
     MS_CHECK_ARG(given || (moments && raster_only), "boundary_stride: MS_BACKWARD_GAUSSIANS, or MS_BACKWARD_RASTER on the moments path");
@@ -336,7 +339,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,
                                             d.raster.compute_point_heuristic ? (float*)gr->point_heuristic : nullptr, s,
-                                            gr->boundary_stride);
+                                            gr->boundary_stride, d.projected_input && gr->stage != MS_BACKWARD_RASTER ? 0 : gr->boundary_form);
   } else {
     MS_CHECK_ARG(gr->grad_points7 || gr->grad_colours, "no gradient accumulator");
     MS_TRY(ms_raster_bwd(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, d.f, &d.raster,
@@ -360,6 +363,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   } else {
     a.grad_points7 = gr->grad_points7; a.grad_colours = gr->grad_colours;
     a.boundary_stride = gr->boundary_stride;
+    a.boundary_cov = given ? gr->boundary_form : 0;
     if (given && gr->gather_world > 0) {
       a.gather_world = gr->gather_world; a.gather_rows = gr->gather_rows;
       a.gather_slots = gr->gather_slots; a.gather_route = gr->gather_route;

@@ -81,7 +81,7 @@ int sh_fwd_inplace_launch(const void* params, const void* positions, const void*
 // row_stride > 0: grad_points7 / grad_features are columns of one row-major array with that many floats per row
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
-                                   hipStream_t s, int row_stride = 0);
+                                   hipStream_t s, int row_stride = 0, int covariance_form = 0);
 
 // ---- tools/experiments/raster_bwd_rows.hip (only with -DMS_WITH_ROWS_KERNEL, tools/build_variant.sh) ------------
 // the round-4 experiment (2x2 quad lists packed by DPP rows): tile 8 / 16; false = not served (tile 32, or
@@ -108,6 +108,7 @@ struct GaussianBwdArgs {
   const int32_t* fixed_exp;  // deterministic: binary exponents of the fixed-point scales (raster_bwd_scan.hip)
   const void* grad_points7;  // (n, 7) or NULL
   const void* grad_colours;  // (n, f) or NULL
+  int boundary_cov;          // rows hold [d mean | dL/d(a, b, c) | 0 | d alpha] (MS_BOUNDARY_COVARIANCE) instead of d(packed 2D)
   int boundary_stride;       // 0: the two arrays above are dense; > 0: floats per row of the array both are columns of
   // gather_world > 0: d(packed 2D gaussian), d(colour) of gaussian i = sum of rows gather_slots[i * gather_world + c],
   // c < gather_route[i] >> 16, of gather_rows (boundary_stride floats per row)

@@ -44,6 +44,7 @@ template <typename T> struct GaussBwdDev {
   const int32_t* fixed_exp;
   const T *grad_points7, *grad_colours;
   int gp_stride, gc_stride;       // floats per row of grad_points7 / grad_colours (7 / f unless interleaved)
+  int boundary_cov;               // given rows are [d mean | dL/d(a, b, c) | 0 | d alpha] (MS_BOUNDARY_COVARIANCE)
   int gather_world;               // > 0: rows gathered from the reverse exchange's receive buffer (frame_internal.h)
   const T* gather_rows;
   const int32_t *gather_slots, *gather_route;
@@ -180,6 +181,11 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         // rasterizer part of (axis, sigma) as a covariance gradient; only the caller's extras go through the eigen chain
         const T gq[7] = {gp[0], gp[1], gx[2], gx[3], gx[4], gx[5], gp[6]};
         project_backward(p, cam, st, gq, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad, gcov);
+      } else if (a.boundary_cov) {
+        // rows from a rank step's strips: the rasterizer's share arrives as a covariance gradient (columns 2..4)
+        const T gq[7] = {gp[0], gp[1], gx[2], gx[3], gx[4], gx[5], gp[6]};
+        const T gc[3] = {gp[2] - gx[2], gp[3] - gx[3], gp[4] - gx[4]};
+        project_backward(p, cam, st, gq, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad, gc);
       } else {
         project_backward(p, cam, st, gp, a.extra_depth ? a.extra_depth[i] : T(0), dp, dls, dq, dal, cam_grad);
       }
@@ -283,6 +289,7 @@ static int launch_typed(const GaussianBwdArgs& g, hipStream_t s) {
   a.grad_points7 = (const T*)g.grad_points7; a.grad_colours = (const T*)g.grad_colours;
   a.gather_world = g.gather_world; a.gather_rows = (const T*)g.gather_rows;
   a.gather_slots = g.gather_slots; a.gather_route = g.gather_route;
+  a.boundary_cov = g.boundary_cov;
   a.gp_stride = g.boundary_stride > 0 ? g.boundary_stride : 7;
   a.gc_stride = g.boundary_stride > 0 ? g.boundary_stride : g.f;
   a.extra_points7 = (const T*)g.extra_points7; a.extra_depth = (const T*)g.extra_depth; a.extra_colours = (const T*)g.extra_colours;

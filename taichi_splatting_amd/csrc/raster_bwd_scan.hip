@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256)
 raster_moments_finalize_kernel(const float* __restrict__ points, float* __restrict__ moments, int64_t n,
                                float* __restrict__ grad_points, float* __restrict__ grad_feats,
                                float* __restrict__ heuristic, const int32_t* __restrict__ fixed_exp,
-                               int gp_stride = 7, int gf_stride = 3) {
+                               int gp_stride = 7, int gf_stride = 3, int covariance_form = 0) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 r0, r1, r2;
@@ -533,10 +533,21 @@ raster_moments_finalize_kernel(const float* __restrict__ points, float* __restri
       const float idet = det != 0.0f ? 1.0f / det : 0.0f;
       o[0] = Sx * A + Sy * C;
       o[1] = Sx * B + Sy * D;
-      o[2] = -(isx * (D * Sxx - B * Sxy) + isy * (A * Syy - C * Sxy)) * idet;
-      o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
-      o[4] = isx * Sxx;
-      o[5] = isy * Syy;
+      if (covariance_form) {
+        // dL/d(a, b, c) of the covariance [[a, b], [b, c]] = U diag(sigma^2) U^T (gaussian_bwd.hip has the derivation):
+        // what the per-gaussian pass of a multi-GPU rank step reads (MS_BOUNDARY_COVARIANCE)
+        const float N00 = Sxx * isx * isx, N01 = Sxy * isx * isy, N11 = Syy * isy * isy;
+        const float uu = ax * ax, ww = ay * ay, uw = ax * ay;
+        o[2] = 0.5f * (N00 * uu - 2.0f * N01 * uw + N11 * ww);
+        o[3] = (N00 - N11) * uw + N01 * (uu - ww);
+        o[4] = 0.5f * (N00 * ww + 2.0f * N01 * uw + N11 * uu);
+        o[5] = 0.0f;
+      } else {
+        o[2] = -(isx * (D * Sxx - B * Sxy) + isy * (A * Syy - C * Sxy)) * idet;
+        o[3] = (isy * (D * Sxy - B * Syy) + isx * (C * Sxx - A * Sxy)) * idet;
+        o[4] = isx * Sxx;
+        o[5] = isy * Syy;
+      }
       o[6] = S / alpha;
     }
   }
@@ -666,12 +677,12 @@ extern "C" int ms_raster_moments_finalize(const void* points7, const float* mome
 namespace ms {
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
-                                   hipStream_t s, int row_stride) {
+                                   hipStream_t s, int row_stride, int covariance_form) {
   if (n == 0) return 0;
   const dim3 grid((unsigned)div_up(n, 256));
   const int gp_stride = row_stride > 0 ? row_stride : 7, gf_stride = row_stride > 0 ? row_stride : 3;
 #define MS_GO(HEUR, FIXED) raster_moments_finalize_kernel<HEUR, FIXED, true><<<grid, 256, 0, s>>>(      \
-      points7, moments, n, grad_points7, grad_features, point_heuristic, fixed_exp, gp_stride, gf_stride)
+      points7, moments, n, grad_points7, grad_features, point_heuristic, fixed_exp, gp_stride, gf_stride, covariance_form)
   if (point_heuristic) { if (deterministic) MS_GO(true, true); else MS_GO(true, false); }
   else { if (deterministic) MS_GO(false, true); else MS_GO(false, false); }
 #undef MS_GO

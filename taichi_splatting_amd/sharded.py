@@ -228,6 +228,7 @@ class _RankStep:
     moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), int(det)))
     if moments_path:
       gr.moments = frame._moments_buffer(device, rows_n, det).data_ptr()
+      gr.boundary_form = _lib.BOUNDARY_COVARIANCE      # the strips hand over dL/d(2D covariance): see include/mi355_splat.h
       gr.deterministic = int(det)
       if det:
         self._fixed_exp = _lib.fixed_point_exponents(g_image)
@@ -333,6 +334,7 @@ class StripStep(_RankStep):
     grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
     g2 = _lib.FrameGradsC()
     g2.stage = _lib.BACKWARD_GAUSSIANS
+    g2.boundary_form = gr.boundary_form
     if in_place:
       g2.grad_points7, g2.grad_colours, g2.boundary_stride = buf.data_ptr(), buf.data_ptr() + 7 * es, width
     else:
@@ -495,6 +497,7 @@ class ShardedStep(_RankStep):
     grads = [torch.empty_like(t) if need[i] else None for i, t in enumerate((pos, lsc, rot, alog))]
     ga = _lib.FrameGradsC()
     ga.stage = _lib.BACKWARD_GAUSSIANS
+    ga.boundary_form = gr.boundary_form
     home = None
     if degree >= 0 or not need[4]:
       # the per-gaussian pass reads every splat's returned rows straight from the receive buffer (summed in copy

@@ -22,7 +22,7 @@ from pathlib import Path
 import torch
 
 TOL = 1e-4
-ROW_BOUND = 2.0e-2          # of the largest gradient; measured worst 3e-3
+ROW_BOUND = 2.0e-3          # of the largest gradient; measured worst 1.1e-4 at config D full size
 _LOG = Path(__file__).resolve().parent.parent / 'gpurun_out' / 'parity_excess.jsonl'
 
 
@@ -54,7 +54,7 @@ def check_pixels(err, pixel_flag, pixel_count, fmax, alpha_threshold, what, max_
   assert int(unexplained.sum()) == 0, (what, f"{int(unexplained.sum())} pixels beyond {TOL} without a near-gate pair", worst)
   if pixel_count is not None and n_over:
     assert bool((err[over] <= bound[over]).all()), (what, "a pixel moved further than its flagged pairs can move it", entry)
-  assert n_over <= max_fraction * total, (what, "too many pixels beyond the tolerance", entry)
+  assert n_over <= max(2, max_fraction * total), (what, "too many pixels beyond the tolerance", entry)
   return entry
 
 
@@ -74,5 +74,5 @@ def check_rows(got, want, splat_flag, what, max_fraction):
   assert int(unexplained.sum()) == 0, (what, f"{int(unexplained.sum())} rows beyond {TOL} of the largest gradient without a "
                                        "near-gate pixel under them", entry)
   assert entry["largest"] <= ROW_BOUND, (what, "a gradient row moved further than flipped gates can move it", entry)
-  assert n_over <= max_fraction * total, (what, "too many gradient rows beyond the tolerance", entry)
+  assert n_over <= max(2, max_fraction * total), (what, "too many gradient rows beyond the tolerance", entry)
   return entry

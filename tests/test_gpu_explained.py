@@ -23,8 +23,8 @@ from .gate_excess import check_pixels, check_rows
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 GATE_EPS = 1e-5       # float32 evaluates alpha_pt * g to a few 1e-6 relative (v_exp_f32 of a 3-term fma chain)
-MAX_PIXELS_BEYOND = 5e-3    # share of the pixels allowed beyond 1e-4 (all of them explained and bounded; measured: see
-MAX_ROWS_BEYOND = 2e-2      # gpurun_out/parity_excess.jsonl / DESIGN.md section 5)
+MAX_PIXELS_BEYOND = 5e-5   # share of pixels / gradient rows allowed beyond 1e-4 on unfiltered scenes (measured at config D
+MAX_ROWS_BEYOND = 1e-5     # full size: 17 of 4.2 M pixels, 1 of 6 M rows); all explained by a near-gate pair AND bounded (gate_excess.py)
 
 
 @pytest.mark.parametrize('tile', [8, 16, 32])

@@ -207,8 +207,8 @@ def test_rank_step_refuses_camera_gradients_and_honours_deterministic():
   step = sharded.StripStep((128, 128), cfg, cam.depth_range, 0, 1, [0, 8])
   mine = g.clone().requires_grad_(True)
   step.probe(mine, cam, True)
-  cam_grad = cam.to(device=DEV)
-  cam_grad.T_camera_world.requires_grad_(True)
+  cam_grad = cam.__class__(projection=cam.projection, T_camera_world=cam.T_camera_world.clone().requires_grad_(True),
+                           near_plane=cam.near_plane, far_plane=cam.far_plane, image_size=cam.image_size)
   with pytest.raises(NotImplementedError, match="camera gradients"):
     step.step(mine, cam_grad, loss_fn, use_sh=True)
 
