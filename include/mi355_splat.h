@@ -328,7 +328,9 @@ typedef struct ms_frame_grads {
                                       never passes through the derivative of the eigen-decomposition (no division by
                                       l1 - l2: float32 rows of nearly isotropic splats keep their digits), and rows of
                                       one gaussian from several strips / ranks simply add.  Multi-GPU rank steps use 1. */
-  int32_t reserved0;
+  int32_t grad_image_broadcast;    /* != 0 (moments path only): grad_image points to ONE pixel's f values, used for every pixel —
+                                      dL/dimage of a sum / mean loss is an expanded scalar, which the caller need not
+                                      materialise as an (H, W, f) array (50 MB at 2048^2 written and read back otherwise) */
 } ms_frame_grads;
 
 enum { MS_BOUNDARY_AXIS_SIGMA = 0, MS_BOUNDARY_COVARIANCE = 1 };

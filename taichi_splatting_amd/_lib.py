@@ -84,7 +84,7 @@ class FrameGradsC(ctypes.Structure):
     ('point_heuristic', c_void_p),
     ('boundary_stride', c_int32), ('gather_world', c_int32),
     ('gather_rows', c_void_p), ('gather_slots', c_void_p), ('gather_route', c_void_p),
-    ('boundary_form', c_int32), ('reserved0', c_int32),
+    ('boundary_form', c_int32), ('grad_image_broadcast', c_int32),
   ]
 
 

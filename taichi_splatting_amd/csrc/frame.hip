@@ -317,6 +317,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
   const bool given = gr->stage == MS_BACKWARD_GAUSSIANS;
   const bool raster_only = gr->stage == MS_BACKWARD_RASTER || d.projected_input;
   const bool moments = !given && frame_uses_moments(desc, gr->deterministic);
+  MS_CHECK_ARG(!gr->grad_image_broadcast || (!given && moments), "grad_image_broadcast: moments path only (float32 RGB, plain pdf)");
   MS_CHECK_ARG(gr->boundary_form == MS_BOUNDARY_AXIS_SIGMA || gr->boundary_form == MS_BOUNDARY_COVARIANCE, "boundary_form");
   MS_CHECK_ARG(gr->boundary_form == 0 || given || (moments && gr->stage == MS_BACKWARD_RASTER),
                "MS_BOUNDARY_COVARIANCE rows: MS_BACKWARD_GAUSSIANS, or MS_BACKWARD_RASTER on the moments path");
@@ -333,8 +334,9 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
       MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
   } else if (moments) {
     MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
-    MS_TRY(ms_raster_bwd_moments(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
-                                 (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end, stream));
+    MS_TRY(raster_bwd_moments_launch(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
+                                     (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end,
+                                     gr->grad_image_broadcast, s));
     if (raster_only)
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,

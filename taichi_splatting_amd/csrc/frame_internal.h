@@ -77,6 +77,12 @@ int sh_fwd_inplace_launch(const void* params, const void* positions, const void*
                           int64_t n, int f, int degree, void* out, int dtype, hipStream_t s);
 
 // ---- raster_bwd_scan.hip ----------------------------------------------------------------------------------------
+// ms_raster_bwd_moments with grad_broadcast: dL/dimage given as ONE pixel's f values (ms_frame_grads.grad_image_broadcast)
+int raster_bwd_moments_launch(const void* points7, const void* features, const int32_t* tile_ranges,
+                              const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
+                              int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
+                              const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
+                              hipStream_t s);
 // ms_raster_moments_finalize that also clears the rows it reads (persistent moments buffer)
 // row_stride > 0: grad_points7 / grad_features are columns of one row-major array with that many floats per row
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,

@@ -147,7 +147,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     float G0 = 0.f, G1 = 0.f, G2 = 0.f, RG = 0.f, T = 0.f;        // T = 0: out-of-image pixels never blend
     if (pix_x < rp.width && pix_y < rp.height) {
       const int64_t p = (int64_t)pix_y * rp.width + pix_x;
-      G0 = grad_image[p * 3 + 0]; G1 = grad_image[p * 3 + 1]; G2 = grad_image[p * 3 + 2];
+      const int64_t gp = rp.grad_broadcast ? 0 : p * 3;
+      G0 = grad_image[gp + 0]; G1 = grad_image[gp + 1]; G2 = grad_image[gp + 2];
       RG = image[p * 3 + 0] * G0 + image[p * 3 + 1] * G1 + image[p * 3 + 2] * G2;   // <R, G>, R = forward image
       T = 1.0f;
     }
@@ -576,7 +577,7 @@ static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
                                 float* moments, int deterministic, const int32_t* fixed_exp, int tile_row_begin,
-                                int tile_row_end, hipStream_t s, const char* who) {
+                                int tile_row_end, hipStream_t s, const char* who, int grad_broadcast = 0) {
   if (deterministic && !fixed_exp) { set_error("%s: deterministic commits need fixed_exp (ms_fixed_point_exponents)", who); return MS_ERR_BAD_ARG; }
   if (image_w <= 0 || image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
   if (!cfg->use_alpha_blending) {
@@ -597,6 +598,7 @@ static int launch_scan_backward(const float* points7, const float* features,
   rp.alpha_threshold = (float)cfg->alpha_threshold;
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
   rp.deterministic = deterministic != 0;
+  rp.grad_broadcast = grad_broadcast != 0;
   rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
 #define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT>                                           \
       <<<dim3(xcd_grid<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, SPLIT * SPLIT)), dim3(TS * TS), 0, s>>>(              \
@@ -675,6 +677,16 @@ extern "C" int ms_raster_moments_finalize(const void* points7, const float* mome
 
 // frame executor (frame_internal.h): finalize + re-zero of the rows it read
 namespace ms {
+int raster_bwd_moments_launch(const void* points7, const void* features, const int32_t* tile_ranges,
+                              const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
+                              int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
+                              const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
+                              hipStream_t s) {
+  return launch_scan_backward((const float*)points7, (const float*)features, tile_ranges, overlap_to_point,
+                              (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
+                              deterministic, fixed_exp, tile_row_begin, tile_row_end, s, "ms_frame_backward", grad_broadcast);
+}
+
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,
                                    int64_t n, float* grad_points7, float* grad_features, float* point_heuristic,
                                    hipStream_t s, int row_stride, int covariance_form) {

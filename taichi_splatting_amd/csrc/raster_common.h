@@ -11,6 +11,8 @@ struct FastParams {
   float clamp_max_alpha, alpha_threshold, one_minus_saturate;
   int deterministic;      // raster_bwd_scan.hip: order-independent (fixed-point integer) gradient commits
   int num_tiles;          // tiles of this launch (xcd_tile)
+  int grad_broadcast;     // raster_bwd_scan.hip: dL/dimage is ONE pixel's f values, the same for every pixel (a sum /
+                          // mean loss hands autograd an expanded scalar: no (H, W, f) copy is made or read)
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share splats (a gaussian

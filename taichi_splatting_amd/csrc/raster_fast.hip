@@ -333,6 +333,7 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
   rp.one_minus_saturate = (float)(1.0 - cfg->saturate_threshold);
   rp.deterministic = 0;
   rp.num_tiles = num_tiles;
+  rp.grad_broadcast = 0;
   return rp;
 }
 

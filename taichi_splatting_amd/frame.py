@@ -537,10 +537,17 @@ class _FrameFunction(torch.autograd.Function):
       return (*zeros, None, None)
 
     w, h = opts.image_size
-    g_image = g_image.contiguous() if g_image is not None else torch.zeros_like(image)
     stream = _lib.current_stream(device)
     det = bool(raster_function.DETERMINISTIC_BACKWARD)
     moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), int(det)))
+    # dL/dimage of a sum / mean loss arrives as an EXPANDED scalar (strides 0): the moments kernel reads one pixel's f
+    # values instead of an (H, W, f) copy that .contiguous() would write and the kernel read back (50 MB at 2048^2)
+    broadcast = (moments_path and g_image is not None and g_image.dim() == 3 and g_image.shape[0] * g_image.shape[1] > 1
+                 and g_image.stride(0) == 0 and g_image.stride(1) == 0)
+    if broadcast:
+      g_image = g_image[0, 0].contiguous()                     # (f,)
+    else:
+      g_image = g_image.contiguous() if g_image is not None else torch.zeros_like(image)
     retained = state.retained()
     want_points = any(kind == 'points7' for _, _, kind in retained)
     # camera pose optimisation with SH colours: the view direction depends on the camera position =
@@ -552,7 +559,8 @@ class _FrameFunction(torch.autograd.Function):
     gr = _lib.FrameGradsC()
     row_bytes = state.y0 * w * image.element_size()          # cropped strip: address of the (absent) row 0
     gr.image = image.data_ptr() - row_bytes * f
-    gr.grad_image = g_image.data_ptr() - row_bytes * f
+    gr.grad_image = g_image.data_ptr() - (0 if broadcast else row_bytes * f)
+    gr.grad_image_broadcast = int(broadcast)
     extras = []
     for name, g in (('extra_points7', g_points7), ('extra_depth', g_depth), ('extra_colours', g_colours)):
       if g is not None:

@@ -279,3 +279,23 @@ def test_reference_tail_lists_reproduce_the_reference_loop_order(tile_size):
     out = rasterize_with_tiles(p.to(DEV), f.to(DEV), o2p_ref, ranges_ref.view(-1, 2), size, cfg)
   assert torch.allclose(out.image.cpu(), want, atol=1e-9)
   assert torch.allclose(out.image_weight.cpu(), want_alpha, atol=1e-9)
+
+
+@pytest.mark.parametrize('crop', [False, True])
+def test_broadcast_image_gradient_needs_no_copy(crop):
+  """image.sum().backward() hands the frame an EXPANDED scalar as dL/dimage; the moments kernel reads it as one pixel's
+  values (ms_frame_grads.grad_image_broadcast).  Same gradients as with a materialised (H, W, 3) array of ones."""
+  g, cam = make_scene(15000, (200, 144), seed=21, sh_degree=2)
+  cfg = RasterConfig()
+  out = []
+  for materialise in (False, True):
+    gd = g.clone().requires_grad_(True)
+    r = frame.render_frame(gd, cam, cfg, True, tile_rows=(2, 7) if crop else None, crop_to_rows=crop)
+    if materialise:
+      (r.image * torch.full_like(r.image, 0.5)).sum().backward()
+    else:
+      (0.5 * r.image.sum()).backward()
+    out.append([t.grad.clone() for t in (gd.position, gd.log_scaling, gd.rotation, gd.alpha_logit, gd.feature)])
+  for a, b in zip(*out):
+    scale = float(b.abs().max())
+    assert scale > 0 and float((a - b).abs().max()) < 5e-5 * scale       # float-atomic noise only
