@@ -49,6 +49,8 @@ _lock = threading.RLock() # guards the caches above and serialises the enqueue o
 
 MOMENTS_LRU = 4           # accumulator buffers kept per device (scene sizes / streams alternating in one process)
 K_SLOTS = 64              # pinned K words per device; a frame holds one from its forward until it has looked at K
+GRAPH_K_WORDS = 1024      # pinned K words per device for frames captured into HIP graphs
+BROADCAST_GRAD = os.environ.get('MS_BROADCAST_GRAD', '1') not in ('', '0')   # A/B switch of grad_image_broadcast
 STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
 host_syncs = 0            # forward-pass waits on the overlap total (non-stalling: the frame is already enqueued)
@@ -80,6 +82,8 @@ def set_overlap_capacity(n: int, image_size, config: RasterConfig, capacity: int
   frame of that shape has run yet)."""
   dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
   _k_capacity[_shape_key(dev, n, image_size, config, tile_rows, use_depth16)] = _round_capacity(capacity)
+  if not torch.cuda.is_current_stream_capturing():
+    _k_ring(dev)               # pinned words must exist before a capture starts
 
 
 def _shape_key(device, n, image_size, config, tile_rows, depth16):
@@ -107,6 +111,20 @@ class KSlots:
     self.view = self.words.numpy()
     self.busy = [False] * K_SLOTS
     self.next = 0
+    # words for frames captured into HIP graphs (kept for the life of the process: a graph replays into its word).
+    # Allocated HERE, in eager mode: pinning host memory inside a stream capture invalidates the capture
+    # (hipHostMalloc is not a capturable call — seen at 6 M gaussians, where torch's host cache had no block to reuse)
+    self.graph_words = torch.zeros((GRAPH_K_WORDS,), dtype=torch.int32).pin_memory()
+    self.graph_view = self.graph_words.numpy()
+    self.graph_next = 0
+
+  def acquire_for_graph(self):
+    with _lock:
+      i = self.graph_next
+      if i >= GRAPH_K_WORDS:
+        raise RuntimeError(f"more than {GRAPH_K_WORDS} frames captured into HIP graphs in this process")
+      self.graph_next = i + 1
+    return self.graph_words[i:i + 1], self.graph_view[i:i + 1]
 
   def acquire(self):
     """(slot index or -1, one-element pinned tensor, its numpy view)"""
@@ -125,12 +143,17 @@ class KSlots:
       self.busy[i] = False
 
 
-def _pinned_k(device):
-  """A pinned int32 word of its own for the frame about to be enqueued: (slot, tensor, numpy view, event, ring)"""
+def _k_ring(device) -> KSlots:
   with _lock:
     ring = _k_host.get(device.index)
     if ring is None:
       ring = _k_host[device.index] = KSlots()
+  return ring
+
+
+def _pinned_k(device):
+  """A pinned int32 word of its own for the frame about to be enqueued: (slot, tensor, numpy view, event, ring)"""
+  ring = _k_ring(device)
   slot, word, view = ring.acquire()
   return slot, word, view, torch.cuda.Event(), ring
 
@@ -187,7 +210,8 @@ def release_caches(force: bool = False):
       _moments_pinned.clear()
     _identity.clear()
     _k_capacity.clear()
-    _k_host.clear()
+    if force:
+      _k_host.clear()          # captured graphs write their overlap totals into these pinned words
 
 
 def identity_indexes(n: int, device) -> torch.Tensor:
@@ -215,6 +239,15 @@ def _moments_buffer(device, n: int, deterministic: bool) -> torch.Tensor:
   key = (device.index, stream, int(n), bool(deterministic))
   with _lock:
     buf = _moments.get(key)
+    if buf is None and torch.cuda.is_current_stream_capturing():
+      # a capture runs on a stream of its own: take the accumulator the eager warm-up frames of this scene size used
+      # (zero between frames) instead of allocating AND ZERO-FILLING a new one inside the graph — the fill would be
+      # replayed with every step (384 MB at 6 M gaussians)
+      for other, cand in _moments.items():
+        if (other[0], other[2], other[3]) == (key[0], key[2], key[3]):
+          buf = _moments[key] = cand
+          _moments_pinned.add(other)
+          break
     if buf is None:
       mine = [k for k in _moments if k[0] == device.index and k not in _moments_pinned]
       for k in mine[:max(0, len(mine) - (MOMENTS_LRU - 1))]:
@@ -313,8 +346,8 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     # a pinned word of the captured frame's own: every replay writes its overlap total there, so the host can tell
     # an overflowed replay (background-only image, zero gradients) WITHOUT touching the device — see check_replays()
     slot, ring, k_event = -1, None, None
-    k_word = torch.full((1,), 0, dtype=torch.int32).pin_memory()
-    k_np = k_word.numpy()
+    k_word, k_np = _k_ring(device).acquire_for_graph()      # pinned in eager mode already (the warm-up frames)
+    k_np[0] = 0
     state.k_word, state.k_view, state.captured = k_word, k_np, True
     _captured_frames.append(weakref.ref(state))
   else:
@@ -542,7 +575,7 @@ class _FrameFunction(torch.autograd.Function):
     moments_path = bool(lib.ms_frame_uses_moments(ctypes.byref(desc), int(det)))
     # dL/dimage of a sum / mean loss arrives as an EXPANDED scalar (strides 0): the moments kernel reads one pixel's f
     # values instead of an (H, W, f) copy that .contiguous() would write and the kernel read back (50 MB at 2048^2)
-    broadcast = (moments_path and g_image is not None and g_image.dim() == 3 and g_image.shape[0] * g_image.shape[1] > 1
+    broadcast = (BROADCAST_GRAD and moments_path and g_image is not None and g_image.dim() == 3 and g_image.shape[0] * g_image.shape[1] > 1
                  and g_image.stride(0) == 0 and g_image.stride(1) == 0)
     if broadcast:
       g_image = g_image[0, 0].contiguous()                     # (f,)

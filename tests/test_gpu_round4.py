@@ -155,6 +155,12 @@ def test_graph_replay_overflow_strict_raises_in_the_step():
   gd, step = _capture_small_step(20000, 4.0)
   r = step()
   del r
+  # nothing may be pinned INSIDE the capture (hipHostMalloc invalidates it): with torch's pinned-memory cache emptied a
+  # pin_memory() call during capture would have to go to the driver — the captured frame's K word comes from a block
+  # pinned in eager mode (frame.KSlots.graph_words); this failed at 6 M gaussians in bench.py's graph child
+  empty = getattr(torch._C, '_host_emptyCache', None)
+  if empty is not None:
+    empty()
   graph = frame.FrameGraph(step, warmup=2, strict=True)
   graph.replay()
   with torch.no_grad():
