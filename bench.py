@@ -621,7 +621,7 @@ def main():
 
 
 COUNTER_FILE = ROOT / 'profiles' / 'raster_bwd_counters.json'
-COUNTER_SOURCES = ('raster_bwd_scan.hip', 'raster_common.h', 'common.h')
+COUNTER_SOURCES = ('raster_bwd_scan.hip', 'raster_bwd_shared.h', 'raster_common.h', 'common.h')
 
 
 def kernel_source_sha16():

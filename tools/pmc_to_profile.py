@@ -27,6 +27,11 @@ Derivations (MI355X_MICROARCH.md, "rocprofv3 PMC slots" / "HBM"):
 import json
 import sys
 
+# Round 4 calibration (tools/ubench_fetch.hip under the same counters, profiles/r04_frame_counters.json): FETCH_SIZE x 1024
+# is EXACTLY half of the bytes read for coalesced 128-bit and 32-bit streams, and 0.49 of the 128-byte lines (0.83-0.96
+# of the 64-byte sectors) touched by random 28- / 32-byte row gathers; WRITE_SIZE x 1024 equals the bytes written.  The
+# x2 therefore applies to every access pattern of these kernels and `traffic_bytes` is 2 x FETCH + WRITE.
+FETCH_CORRECTION = 2.0
 summary, n, size, tile, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 asm = sys.argv[6:8] if len(sys.argv) >= 8 else None
 d = json.load(open(summary))
@@ -48,9 +53,10 @@ def condense(prefix, algorithmic_bytes, mix=None):
   out = {
     "kernel": name.replace('void ', ''),
     "duration_us_under_pmc": round(dur * 1e6, 1),
-    "fetch_bytes_raw": int(c['FETCH_SIZE'] * 1024), "fetch_bytes_x2_upper": int(c['FETCH_SIZE'] * 2048),
+    "fetch_bytes_raw": int(c['FETCH_SIZE'] * 1024), "fetch_bytes": int(c['FETCH_SIZE'] * 1024 * FETCH_CORRECTION),
     "write_bytes": int(c['WRITE_SIZE'] * 1024),
-    "traffic_bytes": int((c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024),
+    "traffic_bytes": int((c['FETCH_SIZE'] * FETCH_CORRECTION + c['WRITE_SIZE']) * 1024),
+    "traffic_bytes_raw": int((c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024),
     "algorithmic_bytes": algorithmic_bytes,
     "compute": {
       "valu_instr_per_launch": int(c['SQ_INSTS_VALU']), "salu_instr_per_launch": int(c['SQ_INSTS_SALU']),
@@ -91,6 +97,8 @@ result = {
               f"tools/prof_raster.py {n} {size} {tile} on one MI355X, condensed by tools/pmc_to_profile.py. Values per launch.",
   "workload": {"n": n, "width": size, "height": size, "tile": tile, "K": k},
   "traffic_bytes": bwd["traffic_bytes"],
+  "traffic_correction": "2 x FETCH_SIZE + WRITE_SIZE (KB x 1024): FETCH_SIZE under-reports by exactly 2 on gfx950 for streams AND "
+                        "for 28-byte row gathers (calibrated: tools/ubench_fetch.hip, profiles/r04_frame_counters.json)",
   "compute": {key: bwd["compute"][key] for key in ("valu_instr_per_s", "peak", "unit", "frac", "static_mix", "valu_busy_model",
                                                      "exec_lane_util", "clock_ghz", "valu_instr_per_launch")},
   "raster_bwd": bwd, "raster_fwd": fwd,
