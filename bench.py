@@ -650,7 +650,8 @@ def load_counters(args, w, h):
   if have != now:
     return None, None, f"stale: collected on kernel sources {have}, this tree is {now} (tools/refresh_profiles.sh)"
   return t.get('traffic_bytes'), t.get('compute'), {"file": str(COUNTER_FILE.relative_to(ROOT)), "kernel_source_sha16": have,
-                                                    "collected": t.get('collected')}
+                                                    "collected": t.get('collected'),
+                                                    "traffic_is": t.get('traffic_correction', "FETCH_SIZE + WRITE_SIZE, raw")}
 
 
 def graph_step_ms_in_child(args):
