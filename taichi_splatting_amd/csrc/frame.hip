@@ -79,7 +79,7 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->cum = scratch_n.take((n + 1) * 4);
   L->ordered_points = scratch_n.take(n * 7 * 4);
   L->points7_f32 = scratch_n.take(d->dtype == MS_F64 ? n * 7 * 4 : 0);
-  const size_t t1 = sort_tmp_size(d->n, 4), t2 = scan_tmp_size(d->n);
+  const size_t t1 = sort_tmp_size(d->n, 4, true), t2 = scan_tmp_size(d->n);
   L->tmp_n = scratch_n.take(t1 > t2 ? t1 : t2);
   L->scratch_n_bytes = scratch_n.off;
 

@@ -42,7 +42,7 @@ __device__ inline void camera_position_solve(const T* __restrict__ m, T* __restr
 
 // ---- scan_sort.hip ----------------------------------------------------------------------------------------------
 size_t scan_tmp_size(int64_t n);
-size_t sort_tmp_size(int64_t n, int key_bytes);
+size_t sort_tmp_size(int64_t n, int key_bytes, bool adaptive = false);   // adaptive: depth_argsort_launch's layout
 // exclusive scan of n int32 into out[0..n] (out[n] = total); the total also goes to *total_host (pinned) and
 // *total_copy (device) when given
 void exclusive_scan_launch(const int32_t* in, int64_t n, int32_t* out, int32_t* total_host, void* tmp, hipStream_t s,

@@ -159,7 +159,6 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   float fixed_main = 0.f, fixed_h0 = 0.f;
   if (rp.deterministic) { fixed_main = ldexpf(1.0f, fixed_exp[0]); fixed_h0 = ldexpf(1.0f, fixed_exp[1]); }
   const float oms = rp.one_minus_saturate;
-  const float gate_e0h = -log2f(rp.alpha_threshold) * GATE_STEP_SCALE;     // gate_step(), raster_common.h
   const uint32_t oms_bits = __float_as_uint(oms);     // T >= 0: the float order is the order of the bit patterns
 
   // accumulators start at zero; the commit of a pass re-zeroes exactly what it read
@@ -356,10 +355,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               const int x = (i + u) & 3, y = i >> 2;
               X[u] = x == 0 ? Xr[y] : __builtin_fmaf(A, (float)x, Xr[y]);
               Y[u] = x == 0 ? Yr[y] : __builtin_fmaf(C, (float)x, Yr[y]);
-              const float e = __builtin_fmaf(X[u], X[u], __builtin_fmaf(Y[u], Y[u], nl2a));
-              const float a_raw = __builtin_amdgcn_exp2f(-e);
+              const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X[u], X[u], __builtin_fmaf(Y[u], Y[u], nl2a)));
               // blend gate (forward.py:99-101): lanes below the threshold carry alpha = 0 from here on
-              a_gated[u] = a_raw * gate_step(e, gate_e0h);          // 0 for idle lanes too (e = +inf)
+              a_gated[u] = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
               a[u] = min_f32_uniform(a_gated[u], rp.clamp_max_alpha);
               om[u] = 1.0f - a[u];
               // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)

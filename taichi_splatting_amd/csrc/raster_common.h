@@ -203,18 +203,6 @@ __device__ __forceinline__ float clamp_alpha(float e, float clamp_max_alpha) {
   return __builtin_amdgcn_fmed3f(e, 0.0f, clamp_max_alpha);
 }
 
-// The blend gate  alpha_pt g > alpha_threshold  (forward.py:99-101) as ARITHMETIC: alpha_pt g = exp2(-e), so the gate is
-// e < E0 = -log2(threshold), and  clamp((E0 - e) * 2^40, 0, 1)  is 1 below E0 and 0 from E0 on — the ramp in between is
-// 9e-13 wide, far below the float32 spacing of e (1e-6 at e ~ 8), so the value is exactly 0 or 1.  One v_fma_f32 with the
-// clamp output modifier and one v_mul_f32 (2 + 2 issue cycles) replace v_cmp + v_cndmask (4 + 4: compares and selects
-// run at half the FMA rate on gfx950, tools/ubench_valu.hip).  A pair within float32 rounding of the gate may fall on the
-// other side than with the compare on exp2(-e) — the same class of deviation every float32 evaluation has there
-// (tests/gate_excess.py counts and bounds it).
-constexpr float GATE_STEP_SCALE = 1099511627776.0f;     // 2^40
-__device__ __forceinline__ float gate_step(float e, float e0_scaled) {
-  return __builtin_amdgcn_fmed3f(__builtin_fmaf(e, -GATE_STEP_SCALE, e0_scaled), 0.0f, 1.0f);
-}
-
 // Lanes of one wave hand data to each other through LDS (hit lists, accumulator rows).  LDS operations of a wave
 // execute in order, but the COMPILER reasons per thread: without a fence it may keep a value this thread loaded earlier
 // instead of re-reading what another lane stored.  Release + acquire at wavefront scope costs no instruction.

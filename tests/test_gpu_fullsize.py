@@ -56,7 +56,14 @@ def test_fullsize_mapper_and_raster_properties(n, size, tile):
   out = rasterize_with_tiles(p, feats, o2p, ranges.view(-1, 2), cam.image_size, cfg_v)
   out.image.sum().backward()
   vis = out.visibility
-  assert torch.allclose(feats.grad[:, 0], vis, rtol=2e-3, atol=2e-3)
+  # forward and backward evaluate the blend gate with their own float32 arithmetic: a (pixel, splat) pair within
+  # rounding of the gate may blend in one pass and not in the other, which moves that gaussian's sum by alpha T <=
+  # alpha_threshold = 1 / 255 per such pair (tools/diag/vis_identity.py: 5 of 1 M, 12 of 6 M gaussians beyond 1e-3,
+  # largest 3.9e-3).  Everything else agrees to summation-order noise; the flipped ones are counted and bounded
+  diff = (feats.grad[:, 0] - vis).abs()
+  flipped = diff > 1e-3 + 2e-3 * vis.abs()
+  assert int(flipped.sum()) <= max(2, int(2e-5 * vis.shape[0])), int(flipped.sum())
+  assert float(diff.max()) <= 2.02 * cfg.alpha_threshold + 2e-3 * float(vis.abs().max()), float(diff.max())
   assert torch.allclose(feats.grad[:, 0], feats.grad[:, 2], rtol=1e-5, atol=1e-6)
   cfg_plain = RasterConfig(tile_size=tile, pixel_stride=cfg.pixel_stride)
   a = rasterize_with_tiles(p, feats.detach(), o2p, ranges.view(-1, 2), cam.image_size, cfg_plain).image
