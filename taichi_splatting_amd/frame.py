@@ -117,13 +117,20 @@ class KSlots:
     self.graph_words = torch.zeros((GRAPH_K_WORDS,), dtype=torch.int32).pin_memory()
     self.graph_view = self.graph_words.numpy()
     self.graph_next = 0
+    self.graph_free = []
 
-  def acquire_for_graph(self):
+  def acquire_for_graph(self, state):
+    """a word for a frame being captured; it returns to the pool when the frame's state (kept alive by the graph's
+    result) is garbage collected"""
     with _lock:
-      i = self.graph_next
-      if i >= GRAPH_K_WORDS:
-        raise RuntimeError(f"more than {GRAPH_K_WORDS} frames captured into HIP graphs in this process")
-      self.graph_next = i + 1
+      if self.graph_free:
+        i = self.graph_free.pop()
+      else:
+        i = self.graph_next
+        if i >= GRAPH_K_WORDS:
+          raise RuntimeError(f"more than {GRAPH_K_WORDS} live frames captured into HIP graphs in this process")
+        self.graph_next = i + 1
+    weakref.finalize(state, self.graph_free.append, i)
     return self.graph_words[i:i + 1], self.graph_view[i:i + 1]
 
   def acquire(self):
@@ -346,7 +353,7 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     # a pinned word of the captured frame's own: every replay writes its overlap total there, so the host can tell
     # an overflowed replay (background-only image, zero gradients) WITHOUT touching the device — see check_replays()
     slot, ring, k_event = -1, None, None
-    k_word, k_np = _k_ring(device).acquire_for_graph()      # pinned in eager mode already (the warm-up frames)
+    k_word, k_np = _k_ring(device).acquire_for_graph(state)      # pinned in eager mode already (the warm-up frames)
     k_np[0] = 0
     state.k_word, state.k_view, state.captured = k_word, k_np, True
     _captured_frames.append(weakref.ref(state))
