@@ -1,0 +1,13 @@
+mkdir -p gpurun_out/r4q
+B="python bench.py --no-cpu-baseline --steps 50 --no-sweep --no-graph"
+pick() { grep -E "timed|stages" | sed 's/\[bench [0-9:]*\] //'; }
+{
+echo "== config D deterministic"; MS_DETERMINISTIC=1 $B 2>&1 | pick
+echo "== config D forward only"; $B --forward-only --no-stages 2>&1 | pick
+echo "== config C"; $B --n 1000000 --size 1920 --height 1080 2>&1 | pick
+echo "== config B"; $B --n 1000000 --size 1024 --sh-degree 0 2>&1 | pick
+echo "== config B forward only"; $B --n 1000000 --size 1024 --sh-degree 0 --forward-only --no-stages 2>&1 | pick
+echo "== config E frame tile16"; $B --size 4096 --steps 20 2>&1 | pick
+echo "== components"; python -m taichi_splatting_amd.benchmarks rasterizer sh projection tilemapper 2>&1 | tail -40
+} > gpurun_out/r4q/round_numbers.txt 2>&1
+cat gpurun_out/r4q/round_numbers.txt
