@@ -600,9 +600,10 @@ def main():
     if compute:
       result["roofline"]["compute"] = compute
     # frame-level fraction: the reference's formula (6-pass 64-bit key sort) and the bytes THIS design moves
-    # (4-pass depth pre-sort of V pairs + ceil(log2 T / 8) passes over K (tile id, point) pairs)
+    # (ceil(log2 T / 8) stable passes over K (tile << 32 | depth key, point) pairs, 12 bytes read + 12 written each,
+    # then the per-tile depth sort: 12 bytes read, 4 written per overlap; csrc/tile_sort.hip)
     own = dict(alg)
-    own['sort'] = 4 * 16 * V + ((max(1, (T - 1).bit_length()) + 7) // 8) * 16 * K
+    own['sort'] = ((max(1, (T - 1).bit_length()) + 7) // 8) * 24 * K + 16 * K
     frame_ref, frame_own = sum(alg.values()), sum(own.values())
     result["frame"] = {"V": V, "K": K, "K_per_N": round(K / args.n, 3), "K_per_tile": round(K / T, 1),
                        "algorithmic_bytes": frame_own, "algorithmic_bytes_reference_sort": frame_ref,

@@ -173,6 +173,16 @@ int ms_segmented_sort_pairs(const int32_t* keys_in, const int32_t* values_in, in
 int ms_find_ranges(const void* sorted_keys, int64_t k, int key_bytes, int tile_shift,
                    int64_t num_tiles, int32_t* out_ranges, void* stream);
 
+/* Per-tile depth sort behind a tile-only sort (the frame executor's mapper, csrc/tile_sort.hip; together with a
+ * stable sort of `tile << 32 | depth key` pairs on bits [32, 32 + tile_bits) it replaces the reference's 6-pass sort
+ * of the whole 64 bit key, tile_mapper.py:148-170, and gives the same order).  sorted_keys (K) u64, grouped by tile
+ * (bits 32..) with a 32 bit depth key below; overlap_to_point (K) the point indices, ascending inside every tile's run
+ * — what a stable sort of a storage-order emission leaves; tile_ranges (num_tiles, 2) from
+ * ms_find_ranges(key_bytes 8, tile_shift 32).  On return every run of overlap_to_point is in (depth key, point index)
+ * order.  sorted_keys is scratch afterwards (long runs are sorted through it); `scratch`: K more u64 words. */
+int ms_tile_depth_sort(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys,
+                       int32_t* overlap_to_point, uint64_t* scratch, void* stream);
+
 /* ---- rasterizer ------------------------------------------------------------------------------
  * _forward_kernel (rasterizer/forward.py:23-135).  points7 (V,7), features (V,F), tile_ranges
  * (T,2) int32 indexed by tile id = tx + ty * ceil(W/tile), overlap_to_point (K) int32.

@@ -105,6 +105,7 @@ SIGNATURES = {
   'ms_radix_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p, POINTER(c_size_t), c_void_p]),
   'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
   'ms_find_ranges': (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
+  'ms_tile_depth_sort': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_fractional_step': (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_morton_codes64': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
   'ms_camera_position': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -10,6 +10,8 @@
 //   * overlap total K: the kernels downstream of the scan read it from `counters` and run on capacity-sized grids.
 //
 // A caller may still LOOK at K (k_host / k_event) — after everything is enqueued — to grow its buffers.
+#include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "frame_internal.h"
 
@@ -86,10 +88,11 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->overlap_to_point = keep_k.take(k * 4);
   L->keep_k_bytes = keep_k.off;
 
-  L->keys = scratch_k.take(k * 4);
+  // 8 byte keys (tile << 32 | depth key) of the direct-order mapper; the pre-sort path (MS_MAPPER=presort) uses half
+  L->keys = scratch_k.take(k * 8);
   L->values = scratch_k.take(k * 4);
-  L->keys_sorted = scratch_k.take(k * 4);
-  L->tmp_k = scratch_k.take(sort_tmp_size(d->k_capacity, 4));
+  L->keys_sorted = scratch_k.take(k * 8);
+  L->tmp_k = scratch_k.take(sort_tmp_size(d->k_capacity, 8));
   L->scratch_k_bytes = scratch_k.off;
 }
 
@@ -119,6 +122,14 @@ __global__ void __launch_bounds__(256)
 f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t count) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = (float)in[i];
+}
+
+// MS_MAPPER=presort: the round-3 mapper (depth pre-sort of the gaussians, overlaps sorted by tile id alone) instead of
+// the direct-order one (overlaps in storage order, stable sort by tile, per-tile depth sort: tile_sort.hip).  Both
+// produce the same overlap_to_point / tile_ranges; read once per process.
+static bool mapper_presort() {
+  static const bool v = [] { const char* e = getenv("MS_MAPPER"); return e && strcmp(e, "presort") == 0; }();
+  return v;
 }
 
 static bool frame_uses_moments(const ms_frame_desc* d, int deterministic) {
@@ -231,11 +242,16 @@ extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_
   int32_t* counts = (int32_t*)(sn + L.counts);
   int32_t* cum = (int32_t*)(sn + L.cum);
   const int cull = d.projected_input ? 0 : 1;
-  // ndc depth (renderer.py:67) is fused into the key generation when a near plane is given
-  depth_argsort_launch(depth, d.n, d.depth16, d.near_plane > 0.0 ? d.near_plane : 0.0, d.far_plane, d.dtype, cull,
-                       sorted_keys, order, sn + L.tmp_n, s);
-  tile_count_launch(points_f32, order, cull ? sorted_keys : nullptr, d.n, g.w_pad, g.h_pad, d.raster.tile_size,
-                    (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counts, (float*)(sn + L.ordered_points), s);
+  if (mapper_presort()) {
+    // ndc depth (renderer.py:67) is fused into the key generation when a near plane is given
+    depth_argsort_launch(depth, d.n, d.depth16, d.near_plane > 0.0 ? d.near_plane : 0.0, d.far_plane, d.dtype, cull,
+                         sorted_keys, order, sn + L.tmp_n, s);
+    tile_count_launch(points_f32, order, cull ? sorted_keys : nullptr, d.n, g.w_pad, g.h_pad, d.raster.tile_size,
+                      (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counts, (float*)(sn + L.ordered_points), s);
+  } else {
+    tile_count_direct_launch(points_f32, cull ? depth : nullptr, d.dtype, d.n, g.w_pad, g.h_pad, d.raster.tile_size,
+                             (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counts, s);
+  }
   exclusive_scan_launch(counts, d.n, cum, k_host, sn + L.tmp_n, s, counters);      // K -> counters[0] and *k_host
   MS_CHECK_LAUNCH();
   if (k_event) MS_CHECK_HIP(hipEventRecord((hipEvent_t)k_event, s));
@@ -275,14 +291,29 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   if (!d.projected_input) MS_TRY(frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_map_raster"));
   if (d.n > 0 && d.k_capacity > 0) {
     MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
-    uint32_t* keys = (uint32_t*)(sk + L.keys);
     int32_t* values = (int32_t*)(sk + L.values);
-    uint32_t* keys_sorted = (uint32_t*)(sk + L.keys_sorted);
-    tile_emit_ordered_launch((const float*)(sn + L.ordered_points), (const int32_t*)(sn + L.order),
-                             (const int32_t*)(sn + L.cum), d.n, g.w_pad, g.h_pad, d.raster.tile_size,
-                             (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counters + 1, keys, values, s);
-    sort_pairs_u32_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, g.tile_bits, sk + L.tmp_k, s);
-    MS_TRY(find_ranges_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s, true));
+    if (mapper_presort()) {
+      uint32_t* keys = (uint32_t*)(sk + L.keys);
+      uint32_t* keys_sorted = (uint32_t*)(sk + L.keys_sorted);
+      tile_emit_ordered_launch((const float*)(sn + L.ordered_points), (const int32_t*)(sn + L.order),
+                               (const int32_t*)(sn + L.cum), d.n, g.w_pad, g.h_pad, d.raster.tile_size,
+                               (float)d.raster.alpha_threshold, g.row_begin, g.row_end, counters + 1, keys, values, s);
+      sort_pairs_u32_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, g.tile_bits, sk + L.tmp_k, s);
+      MS_TRY(find_ranges_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s, true));
+    } else {
+      uint64_t* keys = (uint64_t*)(sk + L.keys);
+      uint64_t* keys_sorted = (uint64_t*)(sk + L.keys_sorted);
+      const void* depth = d.projected_input ? in->depth : (const void*)(kn + L.depth);
+      const float* points_f32 = d.dtype == MS_F64 ? (const float*)(sn + L.points7_f32)
+                                                  : (const float*)(d.projected_input ? in->points7 : (const void*)(kn + L.points7));
+      tile_emit_direct_launch(points_f32, depth, d.dtype, (const int32_t*)(sn + L.cum), d.n, g.w_pad, g.h_pad,
+                              d.raster.tile_size, (float)d.raster.alpha_threshold, g.row_begin, g.row_end, d.depth16,
+                              d.near_plane > 0.0 ? d.near_plane : 0.0, d.far_plane, counters + 1, keys, values, s);
+      sort_pairs_u64_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, 32, 32 + g.tile_bits,
+                                sk + L.tmp_k, s);
+      MS_TRY(find_ranges_u64_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s));
+      tile_depth_sort_launch(ranges, g.num_tiles, keys_sorted, o2p, keys, s);
+    }
   }
   MS_CHECK_LAUNCH();
 

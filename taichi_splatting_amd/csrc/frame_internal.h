@@ -59,6 +59,13 @@ void sort_pairs_u32_dev_launch(const uint32_t* keys_in, const int32_t* vals_in, 
 int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
                            int32_t* out_ranges, hipStream_t s, bool zeroed = false);
 
+// the same on u64 keys, bits [begin_bit, end_bit) (direct-order mapper: tile id in bits 32.., depth key below)
+void sort_pairs_u64_dev_launch(const uint64_t* keys_in, const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out,
+                               int64_t capacity, const int32_t* n_dev, int begin_bit, int end_bit, char* tmp, hipStream_t s);
+// ranges of keys >> 32; the caller has zeroed out_ranges on the stream
+int find_ranges_u64_dev_launch(const uint64_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
+                               int32_t* out_ranges, hipStream_t s);
+
 // ---- mapper.hip -------------------------------------------------------------------------------------------------
 void tile_count_launch(const float* points7, const int32_t* order, const uint32_t* cull_keys, int64_t v, int image_w,
                        int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
@@ -69,6 +76,23 @@ void tile_emit_ordered_launch(const float* ordered_points7, const int32_t* order
                               int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
                               int row_end, const int32_t* k_limit_dev, uint32_t* out_keys, int32_t* out_values,
                               hipStream_t s);
+
+// direct-order mapper of the frame executor (no depth pre-sort): overlap counts in storage order (cull_depth: rows
+// with depth <= 0 overlap nothing), then u64 keys tile << 32 | depth_sort_key and the point index as value
+void tile_count_direct_launch(const float* points7, const void* cull_depth, int dtype, int64_t v, int image_w, int image_h,
+                              int tile_size, float alpha_threshold, int row_begin, int row_end, int32_t* out_counts,
+                              hipStream_t s);
+void tile_emit_direct_launch(const float* points7, const void* depth, int dtype, const int32_t* cum, int64_t v, int image_w,
+                             int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end, int depth16,
+                             double ndc_near, double ndc_far, const int32_t* k_limit_dev, uint64_t* out_keys,
+                             int32_t* out_values, hipStream_t s);
+
+// ---- tile_sort.hip ----------------------------------------------------------------------------------------------
+// Sorts every tile's run of `sorted_keys` (tile << 32 | depth key, already grouped by tile with the point indices in
+// `overlap_to_point` ascending inside each run) by (depth key, point index); only overlap_to_point is rewritten.
+// `scratch`: K u64 words the large-tile path may use (the unsorted key buffer is free by then).
+void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
+                            uint64_t* scratch, hipStream_t s);
 
 // ---- sh.hip -----------------------------------------------------------------------------------------------------
 // SH colours of ALL n gaussians in place (identity index list); rows with depth[i] <= 0 (culled) get zeros and

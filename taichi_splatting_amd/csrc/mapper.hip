@@ -90,6 +90,61 @@ tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ dep
   }
 }
 
+// ---- frame executor, direct order (no depth pre-sort): the gaussians are visited in storage order, the pairs are
+// sorted by tile with a stable radix sort and each tile's run is then depth-sorted on its own (tile_sort.hip).  The
+// result is the same (tile, depth key, point index) order as MODE 0 / MODE 2 above.
+template <typename T>
+__global__ void __launch_bounds__(256)
+tile_count_direct_kernel(const float* __restrict__ points, const T* __restrict__ cull_depth, int64_t v, int image_w,
+                         int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
+                         int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v) return;
+  if (cull_depth && !(cull_depth[i] > T(0))) { counts[i] = 0; return; }      // same rule as DepthPairs::key
+  float g[7];
+  load_point7(points, i, g);
+  const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
+  int count = 0;
+  for (int tv = 0; tv < q.span_y; ++tv) {
+    const int ty = q.min_tile_y + tv;
+    if (ty < row_begin || ty >= row_end) continue;
+    for (int tu = 0; tu < q.span_x; ++tu)
+      if (obb_test_tile(q, tu, tv, tile_size)) ++count;
+  }
+  counts[i] = count;
+}
+
+// key = tile_id << 32 | depth_sort_key(depth) (the 32 bit key of the depth pre-sort), value = point index
+template <typename T>
+__global__ void __launch_bounds__(256)
+tile_emit_direct_kernel(const float* __restrict__ points, const T* __restrict__ depth, const int32_t* __restrict__ cum,
+                        int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold, int row_begin,
+                        int row_end, int depth16, double near_plane, double far_plane,
+                        const int32_t* __restrict__ k_limit, uint64_t* __restrict__ keys, int32_t* __restrict__ values) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= v) return;
+  if (*k_limit == 0) return;                           // overflow of the caller's capacity: write nothing
+  int64_t o = cum[i];
+  if (cum[i + 1] == o) return;                         // culled, or overlaps no tile of this strip
+  float g[7];
+  load_point7(points, i, g);
+  const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
+  const int tiles_wide = image_w / tile_size;
+  const uint64_t depth_key = depth_sort_key(depth[i], depth16, near_plane, far_plane);
+  for (int tu = 0; tu < q.span_x; ++tu) {
+    for (int tv = 0; tv < q.span_y; ++tv) {
+      const int ty = q.min_tile_y + tv;
+      if (ty < row_begin || ty >= row_end) continue;
+      if (obb_test_tile(q, tu, tv, tile_size)) {
+        const uint64_t tile_id = (uint64_t)((int64_t)(q.min_tile_x + tu) + (int64_t)ty * tiles_wide);
+        keys[o] = (tile_id << 32) | depth_key;
+        values[o] = (int32_t)i;
+        ++o;
+      }
+    }
+  }
+}
+
 // 32 bit sort keys of the depth pre-sort: float bits (non-negative depths) or the 16 bit quantisation.
 // near_plane > 0 fuses ndc_depth (torch_lib/projection.py:120-123, renderer.py:67): evaluated in double
 // from the depth's own precision, then rounded once to the float the key is made of.
@@ -117,6 +172,33 @@ void tile_emit_ordered_launch(const float* ordered_points7, const int32_t* order
   tile_emit_kernel<uint32_t, 2><<<dim3((unsigned)div_up(v, 256)), dim3(256), 0, s>>>(
       ordered_points7, nullptr, order, cum, v, image_w, image_h, tile_size, alpha_threshold, row_begin, row_end, 1,
       k_limit_dev, out_keys, out_values);
+}
+
+void tile_count_direct_launch(const float* points7, const void* cull_depth, int dtype, int64_t v, int image_w, int image_h,
+                              int tile_size, float alpha_threshold, int row_begin, int row_end, int32_t* out_counts,
+                              hipStream_t s) {
+  const dim3 grid((unsigned)div_up(v, 256)), block(256);
+  if (dtype == MS_F64)
+    tile_count_direct_kernel<double><<<grid, block, 0, s>>>(points7, (const double*)cull_depth, v, image_w, image_h, tile_size,
+                                                            alpha_threshold, row_begin, row_end, out_counts);
+  else
+    tile_count_direct_kernel<float><<<grid, block, 0, s>>>(points7, (const float*)cull_depth, v, image_w, image_h, tile_size,
+                                                           alpha_threshold, row_begin, row_end, out_counts);
+}
+
+void tile_emit_direct_launch(const float* points7, const void* depth, int dtype, const int32_t* cum, int64_t v, int image_w,
+                             int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end, int depth16,
+                             double ndc_near, double ndc_far, const int32_t* k_limit_dev, uint64_t* out_keys,
+                             int32_t* out_values, hipStream_t s) {
+  const dim3 grid((unsigned)div_up(v, 256)), block(256);
+  if (dtype == MS_F64)
+    tile_emit_direct_kernel<double><<<grid, block, 0, s>>>(points7, (const double*)depth, cum, v, image_w, image_h, tile_size,
+                                                           alpha_threshold, row_begin, row_end, depth16, ndc_near, ndc_far,
+                                                           k_limit_dev, out_keys, out_values);
+  else
+    tile_emit_direct_kernel<float><<<grid, block, 0, s>>>(points7, (const float*)depth, cum, v, image_w, image_h, tile_size,
+                                                          alpha_threshold, row_begin, row_end, depth16, ndc_near, ndc_far,
+                                                          k_limit_dev, out_keys, out_values);
 }
 
 }  // namespace ms

@@ -712,6 +712,37 @@ find_ranges4_kernel(const uint32_t* __restrict__ keys, int64_t capacity, const i
   }
 }
 
+// frame executor, direct-order mapper: tile id = key >> 32 of u64 keys.  Two keys per thread from ONE 128-bit load (a wave
+// reads 2 KB contiguous); the key after them is the neighbour lane's first (lane 63 reads its own)
+__global__ void __launch_bounds__(256)
+find_ranges2_u64_kernel(const uint64_t* __restrict__ keys, int64_t capacity, const int32_t* __restrict__ k_dev,
+                        int64_t num_tiles, int32_t* __restrict__ ranges) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  const int64_t k = k_dev ? (int64_t)*k_dev : capacity;
+  uint32_t t0 = 0xffffffffu, t1 = 0xffffffffu;               // 0xffffffff: no key
+  if (i0 + 1 < k) {
+    const uint4 a = *reinterpret_cast<const uint4*>(keys + i0);
+    t0 = a.y; t1 = a.w;
+  } else if (i0 < k) {
+    t0 = (uint32_t)(keys[i0] >> 32);
+  }
+  uint32_t t2 = (uint32_t)__shfl_down((int)t0, 1);
+  if ((threadIdx.x & 63) == 63) t2 = i0 + 2 < k ? (uint32_t)(keys[i0 + 2] >> 32) : 0xffffffffu;
+  if (i0 >= k) return;
+  if (i0 == 0 && (int64_t)t0 < num_tiles) ranges[(int64_t)t0 * 2 + 0] = 0;
+  const uint32_t t[3] = {t0, t1, t2};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t i = i0 + j;
+    if (i >= k) break;
+    const int64_t tile = t[j], next = (i + 1 < k) ? (int64_t)t[j + 1] : -1;
+    if (tile != next) {
+      if (tile < num_tiles) ranges[tile * 2 + 1] = (int32_t)(i + 1);
+      if (next >= 0 && next < num_tiles) ranges[next * 2 + 0] = (int32_t)(i + 1);
+    }
+  }
+}
+
 // ---- launchers for the frame executor (frame_internal.h) ----------------------------------------------------------
 size_t scan_tmp_size(int64_t n) { return scan_tmp_bytes(n); }
 size_t sort_tmp_size(int64_t n, int key_bytes, bool adaptive) { return sort_tmp_layout(n, key_bytes, adaptive).total; }
@@ -740,6 +771,18 @@ int find_ranges_dev_launch(const uint32_t* sorted_keys, int64_t capacity, const 
   if (num_tiles > 0 && !zeroed) MS_CHECK_HIP(hipMemsetAsync(out_ranges, 0, (size_t)num_tiles * 2 * sizeof(int32_t), s));
   if (capacity > 0)
     find_ranges4_kernel<<<dim3((unsigned)div_up(capacity, 1024)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, num_tiles, out_ranges);
+  return 0;
+}
+
+void sort_pairs_u64_dev_launch(const uint64_t* keys_in, const int32_t* vals_in, uint64_t* keys_out, int32_t* vals_out,
+                               int64_t capacity, const int32_t* n_dev, int begin_bit, int end_bit, char* tmp, hipStream_t s) {
+  radix_sort_passes<uint64_t>(PlainPairs<uint64_t>{keys_in, vals_in}, keys_out, vals_out, capacity, begin_bit, end_bit, tmp, s, n_dev);
+}
+
+int find_ranges_u64_dev_launch(const uint64_t* sorted_keys, int64_t capacity, const int32_t* k_dev, int64_t num_tiles,
+                               int32_t* out_ranges, hipStream_t s) {
+  if (capacity > 0)
+    find_ranges2_u64_kernel<<<dim3((unsigned)div_up(capacity, 512)), dim3(256), 0, s>>>(sorted_keys, capacity, k_dev, num_tiles, out_ranges);
   return 0;
 }
 

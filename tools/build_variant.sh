@@ -10,7 +10,7 @@ out=$root/tools/abl/obj_$name
 mkdir -p "$out"
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-fast-math -fno-slp-vectorize"
 pids=()
-for f in lib projection sh mapper scan_sort raster raster_fast raster_bwd_scan strip_route morton optim gaussian_bwd frame; do
+for f in lib projection sh mapper scan_sort tile_sort raster raster_fast raster_bwd_scan strip_route morton optim gaussian_bwd frame; do
   /opt/rocm/bin/hipcc $flags "$@" -c "$src/$f.hip" -o "$out/$f.o" &
   pids+=($!)
 done
