@@ -269,6 +269,16 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  *     backward -> SH backward; csrc/gaussian_bwd.hip).  ms_frame_uses_moments(desc) != 0: the product raster
  *     backward runs and g->moments (n, MS_MOMENT_ROW) must be zero on entry and is zero again on return;
  *     otherwise g->grad_points7 / grad_colours are zero-initialised accumulators of ms_raster_bwd. */
+/* Two launch sequences build the same overlap_to_point / tile_ranges (same order, ties included):
+ *   MS_MAPPER_DIRECT   overlaps emitted in storage order with keys tile << 32 | depth key, stable sort on the tile bits,
+ *                      per-tile depth sort (ms_tile_depth_sort).  92 bytes moved per overlap, nothing per gaussian
+ *                      beyond the count / emit passes: the faster one up to about 3.5 overlaps per gaussian.
+ *   MS_MAPPER_PRESORT  gaussians sorted by depth first (4 passes over n pairs), overlaps counted and emitted in that
+ *                      order, stable sort of (tile id, point) on the tile bits: 52 bytes per overlap.
+ * The environment variable MS_MAPPER=direct|presort overrides the field for a whole process (A/B runs). */
+#define MS_MAPPER_DIRECT 0
+#define MS_MAPPER_PRESORT 1
+
 typedef struct ms_frame_desc {
   int64_t n;                       /* gaussians = rows of every per-gaussian array */
   int64_t k_capacity;              /* rows of the overlap list */
@@ -279,7 +289,7 @@ typedef struct ms_frame_desc {
   int32_t depth16;                 /* use_depth16 sort keys */
   int32_t tile_row_begin, tile_row_end;   /* multi-GPU strip (0, INT32_MAX: whole image) */
   int32_t projected_input;
-  int32_t reserved;
+  int32_t mapper;                  /* MS_MAPPER_DIRECT / MS_MAPPER_PRESORT: the same in every call of a frame */
   double near_plane, far_plane, blur_cov, clamp_margin;
   ms_raster_config raster;
 } ms_frame_desc;

@@ -21,7 +21,8 @@ LIB_PATH = Path(os.environ.get('MS_SPLAT_LIB') or PACKAGE_DIR / 'libmi355_splat.
 
 MS_F32, MS_F64 = 0, 1
 BACKWARD_ALL, BACKWARD_GAUSSIANS, BACKWARD_RASTER = 0, 1, 2   # ms_frame_grads.stage
-BOUNDARY_AXIS_SIGMA, BOUNDARY_COVARIANCE = 0, 1               # ms_frame_grads.boundary_form
+BOUNDARY_AXIS_SIGMA, BOUNDARY_COVARIANCE = 0, 1
+MAPPER_DIRECT, MAPPER_PRESORT = 0, 1               # ms_frame_grads.boundary_form
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
 
 _lib: Optional[ctypes.CDLL] = None
@@ -49,7 +50,7 @@ class FrameDescC(ctypes.Structure):
     ('image_w', c_int32), ('image_h', c_int32),
     ('dtype', c_int32), ('f', c_int32), ('sh_degree', c_int32), ('depth16', c_int32),
     ('tile_row_begin', c_int32), ('tile_row_end', c_int32),
-    ('projected_input', c_int32), ('reserved', c_int32),
+    ('projected_input', c_int32), ('mapper', c_int32),
     ('near_plane', c_double), ('far_plane', c_double), ('blur_cov', c_double), ('clamp_margin', c_double),
     ('raster', RasterConfigC),
   ]

@@ -49,6 +49,7 @@ static int check_desc(const ms_frame_desc* d, const char* who) {
   if (ts != 8 && ts != 16 && ts != 32) { set_error("%s: tile_size must be 8, 16 or 32 (got %d)", who, ts); return MS_ERR_UNSUPPORTED; }
   if (d->f < 1 || d->f > 4) { set_error("%s: 1..4 colour channels (got %d)", who, d->f); return MS_ERR_UNSUPPORTED; }
   if (d->sh_degree < -1 || d->sh_degree > 3) { set_error("%s: SH degree must be in [0, 3]", who); return MS_ERR_BAD_ARG; }
+  if (d->mapper != MS_MAPPER_DIRECT && d->mapper != MS_MAPPER_PRESORT) { set_error("%s: mapper must be MS_MAPPER_DIRECT or MS_MAPPER_PRESORT (got %d)", who, d->mapper); return MS_ERR_BAD_ARG; }
   if (d->projected_input && d->sh_degree >= 0) { set_error("%s: projected input carries colours, not SH", who); return MS_ERR_BAD_ARG; }
   if (d->depth16) {
     const FrameGeom g = frame_geom(d);
@@ -124,12 +125,17 @@ f64_to_f32_kernel(const double* __restrict__ in, float* __restrict__ out, int64_
   if (i < count) out[i] = (float)in[i];
 }
 
-// MS_MAPPER=presort: the round-3 mapper (depth pre-sort of the gaussians, overlaps sorted by tile id alone) instead of
-// the direct-order one (overlaps in storage order, stable sort by tile, per-tile depth sort: tile_sort.hip).  Both
-// produce the same overlap_to_point / tile_ranges; read once per process.
-static bool mapper_presort() {
-  static const bool v = [] { const char* e = getenv("MS_MAPPER"); return e && strcmp(e, "presort") == 0; }();
-  return v;
+// Which of the two mapper sequences a frame runs (include/mi355_splat.h: MS_MAPPER_DIRECT / MS_MAPPER_PRESORT; both
+// produce the same overlap_to_point / tile_ranges).  MS_MAPPER=direct|presort in the environment overrides the
+// descriptor for the whole process; read once.
+static bool mapper_presort(const ms_frame_desc& d) {
+  static const int forced = [] {
+    const char* e = getenv("MS_MAPPER");
+    if (e && strcmp(e, "presort") == 0) return MS_MAPPER_PRESORT;
+    if (e && strcmp(e, "direct") == 0) return MS_MAPPER_DIRECT;
+    return -1;
+  }();
+  return (forced >= 0 ? forced : d.mapper) == MS_MAPPER_PRESORT;
 }
 
 static bool frame_uses_moments(const ms_frame_desc* d, int deterministic) {
@@ -242,7 +248,7 @@ extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_
   int32_t* counts = (int32_t*)(sn + L.counts);
   int32_t* cum = (int32_t*)(sn + L.cum);
   const int cull = d.projected_input ? 0 : 1;
-  if (mapper_presort()) {
+  if (mapper_presort(d)) {
     // ndc depth (renderer.py:67) is fused into the key generation when a near plane is given
     depth_argsort_launch(depth, d.n, d.depth16, d.near_plane > 0.0 ? d.near_plane : 0.0, d.far_plane, d.dtype, cull,
                          sorted_keys, order, sn + L.tmp_n, s);
@@ -292,7 +298,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   if (d.n > 0 && d.k_capacity > 0) {
     MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
     int32_t* values = (int32_t*)(sk + L.values);
-    if (mapper_presort()) {
+    if (mapper_presort(d)) {
       uint32_t* keys = (uint32_t*)(sk + L.keys);
       uint32_t* keys_sorted = (uint32_t*)(sk + L.keys_sorted);
       tile_emit_ordered_launch((const float*)(sn + L.ordered_points), (const int32_t*)(sn + L.order),

@@ -41,6 +41,11 @@ K_SLACK = 1.25            # capacity = K_SLACK x the largest overlap total seen 
 K_GRANULE = 1 << 16
 
 _k_capacity = {}          # scene-shape key -> overlap-list capacity
+_mapper_mode = {}         # scene-shape key -> _lib.MAPPER_DIRECT / MAPPER_PRESORT (see _choose_mapper)
+# overlaps per gaussian above which the depth pre-sort sequence is the faster mapper, with some hysteresis.  Same box,
+# direct - presort per frame: K/N 2.13 (config D) -0.16 ms, 2.25 (1 M, tile 32) -0.06, 2.59 (3 M) -0.08, 3.34 (1.5 M)
+# -0.04, 3.65 (config D at tile 8) +0.06 (tools/diag/ab_mapper.sh)
+PRESORT_ABOVE, DIRECT_BELOW = 3.6, 3.4
 _k_host = {}              # device index -> KSlots: a ring of pinned int32 words, ONE PER FRAME IN FLIGHT
 _moments = collections.OrderedDict()   # (device index, stream, n, deterministic) -> accumulator rows, zero between frames
 _moments_pinned = set()   # keys whose buffer address is baked into a captured HIP graph: never evicted
@@ -81,9 +86,22 @@ def set_overlap_capacity(n: int, image_size, config: RasterConfig, capacity: int
   """Fix the overlap-list capacity for a scene shape (needed before capturing a frame in a HIP graph when no eager
   frame of that shape has run yet)."""
   dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-  _k_capacity[_shape_key(dev, n, image_size, config, tile_rows, use_depth16)] = _round_capacity(capacity)
+  key = _shape_key(dev, n, image_size, config, tile_rows, use_depth16)
+  _k_capacity[key] = _round_capacity(capacity)
+  _choose_mapper(key, int(capacity / K_SLACK), n)
   if not torch.cuda.is_current_stream_capturing():
     _k_ring(dev)               # pinned words must exist before a capture starts
+
+
+def _choose_mapper(key, k_total: int, n: int):
+  """Remember which launch sequence the next frame of this scene shape maps its tiles with (same lists either way)."""
+  ratio = k_total / max(n, 1)
+  now = _mapper_mode.get(key, _lib.MAPPER_DIRECT)
+  if ratio > PRESORT_ABOVE:
+    now = _lib.MAPPER_PRESORT
+  elif ratio < DIRECT_BELOW:
+    now = _lib.MAPPER_DIRECT
+  _mapper_mode[key] = now
 
 
 def _shape_key(device, n, image_size, config, tile_rows, depth16):
@@ -217,6 +235,7 @@ def release_caches(force: bool = False):
       _moments_pinned.clear()
     _identity.clear()
     _k_capacity.clear()
+    _mapper_mode.clear()
     if force:
       _k_host.clear()          # captured graphs write their overlap totals into these pinned words
 
@@ -346,6 +365,7 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   stream = _lib.current_stream(device)
   capturing = torch.cuda.is_current_stream_capturing()
   capacity = _k_capacity.get(key, 0)
+  desc.mapper = _mapper_mode.get(key, _lib.MAPPER_DIRECT)       # the same in every call of this frame
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")
@@ -404,6 +424,7 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     state.k = k_total
     with _lock:
       _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+      _choose_mapper(key, k_total, desc.n)
 
   state.capacity = 0
   if capacity > 0:
@@ -493,7 +514,7 @@ class _FrameFunction(torch.autograd.Function):
     key = _shape_key(device, n, (w, h), config, opts.tile_rows, opts.use_depth16)
     desc = _lib.FrameDescC(n=n, k_capacity=_k_capacity.get(key, 0), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
                            sh_degree=degree, depth16=int(opts.use_depth16), tile_row_begin=rows[0], tile_row_end=rows[1],
-                           projected_input=0, reserved=0, near_plane=float(opts.depth_range[0]),
+                           projected_input=0, mapper=0, near_plane=float(opts.depth_range[0]),
                            far_plane=float(opts.depth_range[1]), blur_cov=float(config.blur_cov),
                            clamp_margin=float(config.clamp_margin), raster=_lib.raster_config_c(config))
     layout = _lib.FrameLayoutC()
@@ -710,7 +731,7 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     key = ('2d',) + _shape_key(device, n, (w, h), config, None, use_depth16)
     desc = _lib.FrameDescC(n=n, k_capacity=_k_capacity.get(key, 0), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=f,
                            sh_degree=-1, depth16=int(use_depth16), tile_row_begin=0, tile_row_end=1 << 30,
-                           projected_input=1, reserved=0, near_plane=0.0, far_plane=0.0, blur_cov=0.0, clamp_margin=0.0,
+                           projected_input=1, mapper=0, near_plane=0.0, far_plane=0.0, blur_cov=0.0, clamp_margin=0.0,
                            raster=_lib.raster_config_c(config))
     layout = _lib.FrameLayoutC()
     _lib.check(lib.ms_frame_layout_query(ctypes.byref(desc), ctypes.byref(layout)), "rasterize")

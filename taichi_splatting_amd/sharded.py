@@ -79,7 +79,7 @@ def _desc(n, image_size, dtype, f, sh_degree, config, depth_range, tile_rows=Non
   rows = (0, tiles_high) if tile_rows is None else (max(0, int(tile_rows[0])), min(tiles_high, int(tile_rows[1])))
   return _lib.FrameDescC(n=int(n), k_capacity=int(capacity), image_w=w, image_h=h, dtype=_lib.dtype_code(dtype), f=int(f),
                          sh_degree=int(sh_degree), depth16=int(depth16), tile_row_begin=rows[0], tile_row_end=rows[1],
-                         projected_input=int(projected), reserved=0, near_plane=float(depth_range[0]),
+                         projected_input=int(projected), mapper=0, near_plane=float(depth_range[0]),
                          far_plane=float(depth_range[1]), blur_cov=float(config.blur_cov),
                          clamp_margin=float(config.clamp_margin), raster=_lib.raster_config_c(config)), rows
 

@@ -192,3 +192,30 @@ def test_primitive_many_small_tiles_and_one_huge():
   k = sum(lengths)
   run_primitive(lengths, torch.rand(k).view(torch.int32).to(torch.int64))
   run_primitive(lengths, torch.randint(0, 65536, (k,), dtype=torch.int64))     # 16 bit keys
+
+
+def test_both_launch_sequences_give_the_same_lists_and_the_policy_switches():
+  # frame.py remembers per scene shape which sequence the next frame uses (overlaps per gaussian); forced here
+  p, depth, cfg = scene(30000, (192, 128), 3.0, 13)
+  p, depth = p.to(DEV), depth.to(DEV)
+  features = torch.rand(p.shape[0], 3, device=DEV)
+  frame.release_caches()
+  keep = frame.PRESORT_ABOVE, frame.DIRECT_BELOW
+  try:
+    results = []
+    for above, below, want_second in ((1e9, 1e9, 0), (-1.0, -1.0, 1)):
+      frame.release_caches()
+      frame.PRESORT_ABOVE, frame.DIRECT_BELOW = above, below
+      modes = []
+      for _ in range(2):                       # the first frame of a shape maps directly; the second as decided
+        state = frame.FrameState()
+        frame._RasterizeFrameFunction.apply(p, depth, features, (192, 128), cfg, False, state)
+        state.settle()
+        modes.append(int(state.desc.mapper))
+      assert modes == [0, want_second]
+      k = int(state.counters()[0])
+      results.append((state.overlap_to_point()[:k].clone(), state.tile_ranges().clone()))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+  finally:
+    frame.PRESORT_ABOVE, frame.DIRECT_BELOW = keep
+    frame.release_caches()

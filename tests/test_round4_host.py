@@ -66,3 +66,24 @@ def test_visibility_weight_is_the_order4_power_mean():
   assert torch.allclose(running[idx], want, rtol=1e-6)
   assert torch.allclose(w, seen / want, rtol=1e-6)
   assert float(running[1]) == pytest.approx(0.2) and float(running[3]) == 0.0
+
+
+def test_mapper_choice_follows_overlaps_per_gaussian_with_hysteresis():
+  # frame.py picks the mapper's launch sequence per scene shape from the last overlap total (same lists either way):
+  # depth pre-sort above ~3.5 overlaps per gaussian, storage-order emission + per-tile depth sort below
+  from taichi_splatting_amd import _lib, frame
+  key = ('test-shape',)
+  try:
+    n = 1000
+    frame._choose_mapper(key, 2100, n)
+    assert frame._mapper_mode[key] == _lib.MAPPER_DIRECT
+    frame._choose_mapper(key, int(frame.PRESORT_ABOVE * n) + 10, n)
+    assert frame._mapper_mode[key] == _lib.MAPPER_PRESORT
+    frame._choose_mapper(key, int(0.5 * (frame.PRESORT_ABOVE + frame.DIRECT_BELOW) * n), n)                   # inside the band: stays
+    assert frame._mapper_mode[key] == _lib.MAPPER_PRESORT
+    frame._choose_mapper(key, int(frame.DIRECT_BELOW * n) - 10, n)
+    assert frame._mapper_mode[key] == _lib.MAPPER_DIRECT
+    frame._choose_mapper(key, int(0.5 * (frame.PRESORT_ABOVE + frame.DIRECT_BELOW) * n), n)
+    assert frame._mapper_mode[key] == _lib.MAPPER_DIRECT
+  finally:
+    frame._mapper_mode.pop(key, None)
