@@ -51,6 +51,13 @@ alg = [
   ('raster_fwd_f32x3', (4 + 28 + 4 * F) * K + 4 * (F + 1) * P),
   ('raster_bwd_scan', (4 + 28 + 4 * F) * K + 8 * F * P + (28 + 4 * F) * K),
   ('gaussian_bwd', 392 * N),
+  # direct-order mapper (later entries win over the shorter names above)
+  ('tile_count_direct', 36 * N),
+  ('tile_emit_direct', 36 * N + 12 * K),
+  ('radix_upsweep_kernel<unsigned long', 8 * K),
+  ('radix_downsweep_kernel<unsigned long', 24 * K),
+  ('find_ranges2_u64', 8 * K + 8 * T),
+  ('tile_depth_sort_kernel<4>', 16 * K),
 ]
 # the factor FETCH_SIZE under-reports by, measured on the calibration kernels of the same run
 stream = calib.get('calib_stream128', {}).get('FETCH_SIZE_over_read_bytes')
