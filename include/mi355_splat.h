@@ -154,6 +154,16 @@ int ms_tile_emit(const float* points7, const float* depth, const int32_t* order,
                  int points_are_ordered /* points7 is ms_tile_count's ordered copy */,
                  void* out_keys, int32_t* out_values, void* stream);
 
+/* The same emission in storage order (no `order`) with the sort key of ms_depth_sort_keys fused in:
+ * out_keys[o] = (tile_id << 32) | key32(depth[p]) — float bits of the depth, of its ndc value when ndc_near > 0
+ * (torch_lib/projection.py:120-123), or the 16 bit quantisation when depth16 != 0 — and out_values[o] = p.  depth
+ * is float or double (depth_dtype).  Feeds the direct-order mapper: ms_radix_sort_pairs on bits
+ * [32, 32 + tile bits), ms_find_ranges(key_bytes 8, tile_shift 32), ms_tile_depth_sort. */
+int ms_tile_emit_keys64(const float* points7, const void* depth, int depth_dtype, const int32_t* cum, int64_t v,
+                        int image_w, int image_h, int tile_size, float alpha_threshold, int tile_row_begin,
+                        int tile_row_end, int depth16, double ndc_near, double ndc_far, uint64_t* out_keys,
+                        int32_t* out_values, void* stream);
+
 /* cuda_lib.radix_sort_pairs (cuda_lib/radix_sort_pairs.cu:8-70 = cub::DeviceRadixSort::SortPairs):
  * stable LSD radix sort of n (key, int32 value) pairs on key bits [begin_bit, end_bit),
  * out-of-place, inputs preserved.  key_bytes is 4 or 8 (unsigned order). */

@@ -102,6 +102,7 @@ SIGNATURES = {
   'ms_depth_sort_keys': (c_int, [c_void_p, c_int64, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_void_p]),
   'ms_depth_argsort': (c_int, [c_void_p, c_int64, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_void_p]),
   'ms_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_size_t), c_void_p]),
+  'ms_tile_emit_keys64': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
   'ms_tile_emit': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'ms_radix_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, c_int, c_void_p, POINTER(c_size_t), c_void_p]),
   'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -123,7 +123,7 @@ tile_emit_direct_kernel(const float* __restrict__ points, const T* __restrict__ 
                         const int32_t* __restrict__ k_limit, uint64_t* __restrict__ keys, int32_t* __restrict__ values) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
-  if (*k_limit == 0) return;                           // overflow of the caller's capacity: write nothing
+  if (k_limit && *k_limit == 0) return;                // overflow of the caller's capacity: write nothing
   int64_t o = cum[i];
   if (cum[i + 1] == o) return;                         // culled, or overlaps no tile of this strip
   float g[7];
@@ -256,6 +256,27 @@ extern "C" int ms_tile_emit(const float* points7, const float* depth, const int3
   else if (key_mode == 1) MS_EMIT(uint32_t, 1);
   else MS_EMIT(uint32_t, 2);
 #undef MS_EMIT
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_tile_emit_keys64(const float* points7, const void* depth, int depth_dtype, const int32_t* cum, int64_t v,
+                                   int image_w, int image_h, int tile_size, float alpha_threshold, int tile_row_begin,
+                                   int tile_row_end, int depth16, double ndc_near, double ndc_far, uint64_t* out_keys,
+                                   int32_t* out_values, void* stream) {
+  MS_CHECK_ARG(v >= 0, "v < 0");
+  MS_CHECK_ARG(depth_dtype == MS_F32 || depth_dtype == MS_F64, "depth_dtype must be MS_F32 or MS_F64");
+  MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
+  MS_CHECK_ARG(image_w % tile_size == 0 && image_h % tile_size == 0, "image size must be padded to the tile size");
+  if (depth16) {
+    const int64_t tiles = (int64_t)(image_w / tile_size) * (image_h / tile_size);
+    MS_CHECK_ARG(tiles <= 65536, "use_depth16 keys hold a 16 bit tile id: too many tiles");   // tile_mapper.py:49-53
+  }
+  if (v == 0) return 0;
+  MS_CHECK_ARG(points7 && depth && cum && out_keys && out_values, "null pointer");
+  tile_emit_direct_launch(points7, depth, depth_dtype, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin,
+                          tile_row_end, depth16, ndc_near > 0.0 ? ndc_near : 0.0, ndc_far, nullptr, out_keys, out_values,
+                          (hipStream_t)stream);
   MS_CHECK_LAUNCH();
   return 0;
 }

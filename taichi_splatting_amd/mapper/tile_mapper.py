@@ -22,6 +22,11 @@ from .. import _lib
 from ..data_types import RasterConfig
 
 
+# overlaps per gaussian above which the pre-sort sequence moves fewer bytes than the direct one (frame.py has the
+# measurements; there the choice is made from the previous frame's total, here from this call's own)
+PRESORT_ABOVE = 3.5
+
+
 def pad_to_tile(image_size: Tuple[Integral, Integral], tile_size: int):
   def pad(x):
     return int(math.ceil(x / tile_size) * tile_size)
@@ -32,8 +37,14 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                        image_size: Tuple[Integral, Integral], config: RasterConfig,
                        use_depth16: bool = False,
                        tile_rows: Optional[Tuple[int, int]] = None,
-                       ndc_range: Optional[Tuple[float, float]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                       ndc_range: Optional[Tuple[float, float]] = None,
+                       method: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor]:
   """``map_to_tiles`` restricted to tile rows [tile_rows[0], tile_rows[1]) (multi-GPU strips).
+
+  ``method``: ``'direct'`` (storage-order emission, stable sort on the tile bits, per-tile depth sort) or
+  ``'presort'`` (gaussians sorted by depth first, overlaps sorted by tile id) — two constructions of the SAME lists
+  (tile, depth key, point index); ``None`` picks by overlaps per gaussian (``PRESORT_ABOVE``), which is known here
+  before anything is emitted.
 
   ``tile_ranges`` is still indexed by the global tile id; tiles outside the strip are empty.
   ``ndc_range=(near, far)``: ``depth`` holds camera depths and is converted to ndc depth inside the
@@ -74,22 +85,64 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     def scratch(nbytes):
       return torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
 
-    def sort_pairs(keys_in, vals_in, key_bytes, end_bit):
+    def sort_pairs(keys_in, vals_in, key_bytes, begin_bit, end_bit):
       n = keys_in.shape[0]
       keys_out, vals_out = torch.empty_like(keys_in), torch.empty_like(vals_in)
       nb = ctypes.c_size_t(0)
-      _lib.check(lib.ms_radix_sort_pairs(None, None, None, None, n, key_bytes, 0, end_bit, None,
+      _lib.check(lib.ms_radix_sort_pairs(None, None, None, None, n, key_bytes, begin_bit, end_bit, None,
                                          ctypes.byref(nb), stream), "map_to_tiles")
       tmp = scratch(nb.value)
       _lib.check(lib.ms_radix_sort_pairs(keys_in.data_ptr(), vals_in.data_ptr(), keys_out.data_ptr(),
-                                         vals_out.data_ptr(), n, key_bytes, 0, end_bit, tmp.data_ptr(),
+                                         vals_out.data_ptr(), n, key_bytes, begin_bit, end_bit, tmp.data_ptr(),
                                          ctypes.byref(nb), stream), "map_to_tiles")
       return keys_out, vals_out
 
-    # 1. depth pre-sort of the V gaussians (stable: ties keep point order): 32 bit keys, 4 radix passes over V pairs
-    #    (2 for depth16) instead of 4 of the 6 passes over the K overlaps; the first pass makes the keys from the
-    #    depths itself (ms_depth_argsort)
     near, far = (0.0, 0.0) if ndc_range is None else (float(ndc_range[0]), float(ndc_range[1]))
+    tile_bits = max(1, (num_tiles - 1).bit_length())
+
+    def exclusive_scan(counts, want_total):
+      cum = torch.empty((v + 1,), dtype=torch.int32, device=device)
+      nbytes = ctypes.c_size_t(0)
+      _lib.check(lib.ms_exclusive_scan_i32(None, v, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
+      tmp = scratch(nbytes.value)
+      _lib.check(lib.ms_exclusive_scan_i32(counts.data_ptr(), v, cum.data_ptr(), None, tmp.data_ptr(),
+                                           ctypes.byref(nbytes), stream), "map_to_tiles")
+      return cum, (int(cum[v].item()) if want_total else None)
+
+    # 1. overlap counts in storage order (a streaming pass), exclusive scan, total K (the one host sync of the mapper)
+    counts = torch.empty((v,), dtype=torch.int32, device=device)
+    _lib.check(lib.ms_tile_count(points.data_ptr(), None, v, w_pad, h_pad, tile_size, config.alpha_threshold,
+                                 row_begin, row_end, counts.data_ptr(), None, stream), "map_to_tiles")
+    cum, total = exclusive_scan(counts, True)
+    if total < 0:
+      raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
+                          "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
+    if total == 0:
+      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
+    if method is None:
+      method = 'presort' if total > PRESORT_ABOVE * v else 'direct'
+
+    if method == 'direct':
+      # 2. keys tile << 32 | depth key (ndc / 16 bit quantisation fused) in storage order; 3. STABLE sort on the tile
+      #    bits only: every tile's run keeps ascending point indices; 4. ranges; 5. each run sorted by (depth key,
+      #    point index) by one workgroup (csrc/tile_sort.hip).  Same lists as the full 64 bit sort, 2 passes over K.
+      keys = torch.empty((total,), dtype=torch.int64, device=device)
+      values = torch.empty((total,), dtype=torch.int32, device=device)
+      _lib.check(lib.ms_tile_emit_keys64(points.data_ptr(), depths.data_ptr(), _lib.dtype_code(depths.dtype), cum.data_ptr(),
+                                         v, w_pad, h_pad, tile_size, config.alpha_threshold, row_begin, row_end,
+                                         int(use_depth16), near, far, keys.data_ptr(), values.data_ptr(), stream),
+                 "map_to_tiles")
+      keys_sorted, overlap_to_point = sort_pairs(keys, values, 8, 32, 32 + tile_bits)
+      _lib.check(lib.ms_find_ranges(keys_sorted.data_ptr(), total, 8, 32, num_tiles, tile_ranges.data_ptr(), stream),
+                 "map_to_tiles")
+      _lib.check(lib.ms_tile_depth_sort(tile_ranges.data_ptr(), num_tiles, keys_sorted.data_ptr(),
+                                        overlap_to_point.data_ptr(), keys.data_ptr(), stream), "map_to_tiles")
+      return overlap_to_point, tile_ranges
+
+    assert method == 'presort', f"map_to_tiles: unknown method {method!r}"
+    # 2. depth pre-sort of the V gaussians (stable: ties keep point order): 32 bit keys, 4 radix passes over V pairs
+    #    (2 for depth16; passes whose digit is the same in every key are skipped) instead of 4 of the 6 passes over
+    #    the K overlaps; the first pass makes the keys from the depths itself (ms_depth_argsort)
     sorted_keys = torch.empty((v,), dtype=torch.int32, device=device)
     order = torch.empty((v,), dtype=torch.int32, device=device)
     nb = ctypes.c_size_t(0)
@@ -100,42 +153,30 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                                     sorted_keys.data_ptr(), order.data_ptr(), tmp.data_ptr(), ctypes.byref(nb), stream),
                "map_to_tiles")
 
-    # 2. overlap counts in depth order, exclusive scan, total K (the one host sync of the mapper)
-    counts = torch.empty((v,), dtype=torch.int32, device=device)
+    # 3. overlap counts again, in depth order, with the depth-ordered copy of the rows the emit re-reads linearly
     ordered = torch.empty((v, 7), dtype=torch.float32, device=device)
     _lib.check(lib.ms_tile_count(points.data_ptr(), order.data_ptr(), v, w_pad, h_pad, tile_size,
                                  config.alpha_threshold, row_begin, row_end, counts.data_ptr(),
                                  ordered.data_ptr(), stream), "map_to_tiles")
-    cum = torch.empty((v + 1,), dtype=torch.int32, device=device)
-    nbytes = ctypes.c_size_t(0)
-    _lib.check(lib.ms_exclusive_scan_i32(None, v, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
-    tmp = scratch(nbytes.value)
-    _lib.check(lib.ms_exclusive_scan_i32(counts.data_ptr(), v, cum.data_ptr(), None, tmp.data_ptr(),
-                                         ctypes.byref(nbytes), stream), "map_to_tiles")
-    total = int(cum[v].item())
-    if total < 0:
-      raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
-                          "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-    if total == 0:
-      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
+    cum, _ = exclusive_scan(counts, False)
 
-    # 3. emit (tile id, point) in depth order; 4. STABLE sort on the tile id bits only
+    # 4. emit (tile id, point) in depth order; 5. STABLE sort on the tile id bits only
     keys = torch.empty((total,), dtype=torch.int32, device=device)
     values = torch.empty((total,), dtype=torch.int32, device=device)
     _lib.check(lib.ms_tile_emit(ordered.data_ptr(), None, order.data_ptr(), cum.data_ptr(), v, w_pad, h_pad,
                                 tile_size, config.alpha_threshold, row_begin, row_end, 2, 1,
                                 keys.data_ptr(), values.data_ptr(), stream), "map_to_tiles")
-    tile_bits = max(1, (num_tiles - 1).bit_length())
-    keys_sorted, overlap_to_point = sort_pairs(keys, values, 4, tile_bits)
+    keys_sorted, overlap_to_point = sort_pairs(keys, values, 4, 0, tile_bits)
 
-    # 5. per-tile ranges
+    # 6. per-tile ranges
     _lib.check(lib.ms_find_ranges(keys_sorted.data_ptr(), total, 4, 0, num_tiles,
                                   tile_ranges.data_ptr(), stream), "map_to_tiles")
     return overlap_to_point, tile_ranges
 
 
 def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple[Integral, Integral],
-                 config: RasterConfig, use_depth16: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+                 config: RasterConfig, use_depth16: bool = False, *, method: Optional[str] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
   """Maps gaussians to tiles, sorted by depth (front to back).
 
   Parameters:
@@ -148,7 +189,7 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     overlap_to_point: (K,) int32, overlap index -> point index
     tile_ranges: (TH, TW, 2) int32, tile -> [start, end) range of overlap indices
   """
-  return map_to_tiles_strip(gaussians, depth, image_size, config, use_depth16=use_depth16)
+  return map_to_tiles_strip(gaussians, depth, image_size, config, use_depth16=use_depth16, method=method)
 
 
 def with_reference_tail(overlap_to_point: torch.Tensor, tile_ranges: torch.Tensor, tile_size: int,

@@ -16,10 +16,16 @@ DEV = 'cuda:0'
 
 
 def _check(p, depth, size, cfg, use_depth16=False, tile_rows=None):
-  if tile_rows is None:
-    o2p, ranges = map_to_tiles(p.to(DEV), depth.to(DEV), size, cfg, use_depth16=use_depth16)
-  else:
-    o2p, ranges = map_to_tiles_strip(p.to(DEV), depth.to(DEV), size, cfg, use_depth16=use_depth16, tile_rows=tile_rows)
+  # both constructions of the lists (tile_mapper.py: 'direct' and 'presort') against the oracle, and each other
+  a = _check_method(p, depth, size, cfg, use_depth16, tile_rows, 'direct')
+  b = _check_method(p, depth, size, cfg, use_depth16, tile_rows, 'presort')
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+  return a
+
+
+def _check_method(p, depth, size, cfg, use_depth16, tile_rows, method):
+  o2p, ranges = map_to_tiles_strip(p.to(DEV), depth.to(DEV), size, cfg, use_depth16=use_depth16, tile_rows=tile_rows,
+                                   method=method)
   w_o2p, w_ranges, _ = omap.map_to_tiles(p.numpy(), depth.numpy(), size, cfg.tile_size, cfg.alpha_threshold,
                                          use_depth16=use_depth16, tile_rows=tile_rows)
   assert o2p.dtype == torch.int32 and ranges.dtype == torch.int32

@@ -1,6 +1,7 @@
 """-m gpu: the frame executor's direct-order mapper (storage-order emission -> stable sort by tile -> per-tile depth
-sort, csrc/tile_sort.hip) against the modular mapper (one 64 bit sort of tile << 32 | depth bits, the reference's
-mapper/tile_mapper.py:115-170 structure, itself held against the numpy oracle in test_gpu_mapper.py).  Integer outputs:
+sort, csrc/tile_sort.hip) against the pre-sort construction of the same lists (gaussians sorted by depth, overlaps
+sorted by tile id: map_to_tiles(method='presort'); both are held against the numpy oracle in test_gpu_mapper.py, which
+restates the reference's one sort of tile << 32 | depth bits, mapper/tile_mapper.py:115-170).  Integer outputs:
 overlap_to_point and tile_ranges must be IDENTICAL — same (tile, depth key, point index) order, ties included.
 
 The scenes aim at the branches of tile_sort.hip: runs in each of the three LDS size classes (up to 1024 / 2560 / 5120 entries) and above them,
@@ -28,8 +29,10 @@ def executor_map(p, depth, features, size, cfg, use_depth16=False):
 def check(p, depth, size, cfg, use_depth16=False):
   p, depth = p.to(DEV), depth.to(DEV)
   features = torch.rand(p.shape[0], 3, device=DEV)
-  want_o2p, want_ranges = map_to_tiles(p, depth.reshape(-1, 1), size, cfg, use_depth16=use_depth16)
+  want_o2p, want_ranges = map_to_tiles(p, depth.reshape(-1, 1), size, cfg, use_depth16=use_depth16, method='presort')
   o2p, ranges = executor_map(p, depth, features, size, cfg, use_depth16)
+  m_o2p, m_ranges = map_to_tiles(p, depth.reshape(-1, 1), size, cfg, use_depth16=use_depth16, method='direct')
+  assert torch.equal(m_ranges, want_ranges) and torch.equal(m_o2p, want_o2p)       # the modular operator's own direct path
   assert torch.equal(ranges, want_ranges)
   assert o2p.shape == want_o2p.shape
   bad = (o2p != want_o2p).nonzero()
@@ -130,7 +133,8 @@ def test_render_path_with_culled_rows_and_ndc_keys(use_depth16):
   pts = r.points
   assert 0 < pts.idx.numel() < g.position.shape[0]                          # something was culled
   want_o2p, want_ranges = map_to_tiles_strip(pts.gaussians2d.detach(), pts.depths.detach().reshape(-1, 1), image_size=cam.image_size,
-                                             config=cfg, use_depth16=use_depth16, ndc_range=(cam.near_plane, cam.far_plane))
+                                             config=cfg, use_depth16=use_depth16, ndc_range=(cam.near_plane, cam.far_plane),
+                                             method='presort')
   assert torch.equal(ranges, want_ranges.view_as(ranges))
   assert torch.equal(o2p, pts.idx.reshape(-1).to(torch.int32)[want_o2p.long()])
 
