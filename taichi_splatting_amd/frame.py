@@ -94,10 +94,14 @@ def set_overlap_capacity(n: int, image_size, config: RasterConfig, capacity: int
 
 
 def _choose_mapper(key, k_total: int, n: int):
-  """Remember which launch sequence the next frame of this scene shape maps its tiles with (same lists either way)."""
+  """Remember which launch sequence the next frame of this scene shape maps its tiles with (same lists either way).
+  16 bit depth keys (the last entry of a shape key) always take the pre-sort: two passes over n pairs instead of four,
+  4-byte pairs through the tile sort (1 M gaussians, K / n 2.45: 0.148 ms against 0.185)."""
   ratio = k_total / max(n, 1)
   now = _mapper_mode.get(key, _lib.MAPPER_DIRECT)
-  if ratio > PRESORT_ABOVE:
+  if key and key[-1] is True:
+    now = _lib.MAPPER_PRESORT
+  elif ratio > PRESORT_ABOVE:
     now = _lib.MAPPER_PRESORT
   elif ratio < DIRECT_BELOW:
     now = _lib.MAPPER_DIRECT
@@ -365,7 +369,8 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   stream = _lib.current_stream(device)
   capturing = torch.cuda.is_current_stream_capturing()
   capacity = _k_capacity.get(key, 0)
-  desc.mapper = _mapper_mode.get(key, _lib.MAPPER_DIRECT)       # the same in every call of this frame
+  # the same in every call of this frame; before the first frame of a shape only the key width is known
+  desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")

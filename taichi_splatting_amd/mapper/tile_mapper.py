@@ -120,7 +120,8 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     if total == 0:
       return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
     if method is None:
-      method = 'presort' if total > PRESORT_ABOVE * v else 'direct'
+      # 16 bit keys: the pre-sort is two passes over v pairs and the tile sort moves 4-byte keys — always cheaper
+      method = 'presort' if (use_depth16 or total > PRESORT_ABOVE * v) else 'direct'
 
     if method == 'direct':
       # 2. keys tile << 32 | depth key (ndc / 16 bit quantisation fused) in storage order; 3. STABLE sort on the tile

@@ -1,0 +1,9 @@
+B="python bench.py --no-cpu-baseline --steps 50 --no-sweep --no-graph"
+pick() { grep -E "timed|stages" | sed 's/\[bench [0-9:]*\] //'; }
+echo "== config D deterministic"; MS_DETERMINISTIC=1 $B 2>&1 | pick
+echo "== config D forward only"; $B --forward-only --no-stages 2>&1 | pick
+echo "== config C"; $B --n 1000000 --size 1920 --height 1080 2>&1 | pick
+echo "== config B"; $B --n 1000000 --size 1024 --sh-degree 0 2>&1 | pick
+echo "== config B forward only"; $B --n 1000000 --size 1024 --sh-degree 0 --forward-only --no-stages 2>&1 | pick
+echo "== config E frame tile16"; $B --size 4096 --steps 20 2>&1 | pick
+echo "== components"; python -m taichi_splatting_amd.benchmarks tilemapper 2>&1 | tail -6
