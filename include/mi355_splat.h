@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_VERSION 302  /* 0.3.2: frame executor; row-strided / gathered 2D-boundary gradients for the rank steps */
+#define MS_VERSION 400  /* 0.4.0: ms_frame_desc.mapper, ms_tile_depth_sort, ms_tile_emit_keys64; ms_frame_grads.boundary_form / grad_image_broadcast */
 
 enum { MS_F32 = 0, MS_F64 = 1 };
 

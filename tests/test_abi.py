@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_error_string(lib):
-  assert lib.ms_version() == 302     # MS_VERSION of include/mi355_splat.h (0.3.2: row-strided / gathered boundary gradients)
+  assert lib.ms_version() == 400     # MS_VERSION of include/mi355_splat.h (0.4.0: mapper selector, per-tile depth sort)
   assert isinstance(lib.ms_last_error_string(), bytes)
 
 
