@@ -24,7 +24,9 @@
 //   * what a lane accumulates are the six moments  sum q, q X, q Y, q X^2, q X Y, q Y^2  (q = alpha g dL/dalpha,
 //     (X, Y) = pixel in the splat's normalised frame) plus sum w G_c: every geometric gradient of
 //     generic.py:321-336 is a per-splat LINEAR map of these sums, applied once per gaussian by
-//     raster_moments_finalize_kernel (or by the fused projection/SH backward) instead of once per pixel;
+//     raster_moments_finalize_kernel (or by the fused projection/SH backward) instead of once per pixel.  Inside a
+//     chunk the moments are first taken in the sub-patch's integer pixel grid (x, y in 0..3 are compile-time constants
+//     of the unrolled steps: 75 instead of 128 instructions per chunk) and mapped to (X, Y) once per chunk (round 4);
 //   * a chunk ends with a plain read-add-write of the lane's sums into the WAVE'S OWN LDS row of that splat (LDS
 //     float atomics cost ~160 cycles per instruction on gfx950 and are avoided), and a pass over the staged batch
 //     ends with ONE 64-byte, line-aligned row of global float atomics per (8x8 patch, splat): seven rows of nine
@@ -44,6 +46,9 @@
 #endif
 #ifndef MS_SCAN_ABLATE
 #define MS_SCAN_ABLATE 0
+#endif
+#ifndef MS_GRID_MOMENTS
+#define MS_GRID_MOMENTS 1           // 0: per-pixel moment sums in the splat's frame (rounds 2-3), kept for A/B builds
 #endif
 // tile 32 (one 1024-thread workgroup per tile): staged splats per batch / accumulator rows per wave
 // tile 8 (one wave per tile)
@@ -110,6 +115,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
   constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : MS_T8_CAP;
   constexpr int NACC = HEUR ? 11 : 9;
+  constexpr bool GRID_MOMENTS = !HEUR && MS_GRID_MOMENTS != 0;   // see the blend loop
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and PRIMARY + t)
   constexpr int PRIMARY = THREADS < BATCH ? THREADS : BATCH;      // slots filled by "thread t stages slot t"
   constexpr int SLOTS_B = PIPELINED ? BATCH - PRIMARY : 0;  // second slot of the first SLOTS_B threads
@@ -321,6 +327,13 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
           float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
           float h0 = 0.f, h1 = 0.f;
+          // GRID_MOMENTS (no heuristics): the six moments are first taken in the sub-patch's own pixel grid,
+          //   n = sum q {1, x, y, x^2, x y, y^2},  x, y in 0..3,
+          // where x and y are compile-time constants of the unrolled steps: a pixel row keeps r = sum_x q {1, x, x^2}
+          // (7 additions / FMAs for its four pixels), a row end folds r into n with the constants y, y^2 (3 to 6), and
+          // the chunk ends with the affine change of variables X = X00 + A x + B y, Y = Y00 + C x + D y (26) — 75
+          // instructions per chunk instead of 16 x 8.
+          float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f, n4 = 0.f, n5 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #if MS_SCAN_STATS
           int steps_run = 0, lanes_contrib = 0;
 #endif
@@ -347,7 +360,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
             }
             // wave-uniform: a group of saturated / out-of-image pixels is skipped; if only some of them are dead, their
             // lanes all find T <= 1 - saturate_threshold below and contribute nothing
-            if (__ballot(any_alive) == 0) continue;
+            if (__ballot(any_alive) != 0) {
 
             float X[U], Y[U], a_gated[U], a[U], om[U], Tk[U];
 #pragma unroll
@@ -405,8 +418,15 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
               const float q_ = ag * a_st[u];
               const float qX = q_ * X[u], qY = q_ * Y[u];
-              m0 += q_; m1 += qX; m2 += qY;
-              m3 = __builtin_fmaf(qX, X[u], m3); m4 = __builtin_fmaf(qX, Y[u], m4); m5 = __builtin_fmaf(qY, Y[u], m5);
+              if (GRID_MOMENTS) {
+                const int x = (i + u) & 3;                          // compile-time in the unrolled loop
+                r0 += q_;
+                if (x == 1) { r1 += q_; r2 += q_; }
+                if (x > 1) { r1 = __builtin_fmaf(q_, (float)x, r1); r2 = __builtin_fmaf(q_, (float)(x * x), r2); }
+              } else {
+                m0 += q_; m1 += qX; m2 += qY;
+                m3 = __builtin_fmaf(qX, X[u], m3); m4 = __builtin_fmaf(qX, Y[u], m4); m5 = __builtin_fmaf(qY, Y[u], m5);
+              }
               a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
               if (HEUR) {                                           // backward.py:190-194
                 const float agm = a_st[u] != 0.0f ? ag : 0.0f;
@@ -420,6 +440,29 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #if MS_SCAN_STATS
             steps_run += U;
 #endif
+            }
+            if (GRID_MOMENTS && (i & 3) == 2) {                     // end of pixel row y: fold it into the grid moments
+              const int y = i >> 2;
+              n0 += r0; n1 += r1; n3 += r2;
+              if (y == 1) { n2 += r0; n4 += r1; n5 += r0; }
+              if (y > 1) {
+                n2 = __builtin_fmaf(r0, (float)y, n2); n4 = __builtin_fmaf(r1, (float)y, n4);
+                n5 = __builtin_fmaf(r0, (float)(y * y), n5);
+              }
+              r0 = 0.f; r1 = 0.f; r2 = 0.f;
+            }
+          }
+          if (GRID_MOMENTS) {
+            // X = X00 + A x + B y,  Y = Y00 + C x + D y:  sums of q {1, X, Y, X^2, X Y, Y^2} from the grid moments
+            const float P = __builtin_fmaf(A, n1, B * n2), Q = __builtin_fmaf(C, n1, D * n2);
+            const float s1 = __builtin_fmaf(A, n3, B * n4), s2 = __builtin_fmaf(A, n4, B * n5);
+            const float t1 = __builtin_fmaf(C, n3, D * n4), t2 = __builtin_fmaf(C, n4, D * n5);
+            m0 = n0;
+            m1 = __builtin_fmaf(X00, n0, P);
+            m2 = __builtin_fmaf(Y00, n0, Q);
+            m3 = __builtin_fmaf(X00, m1 + P, __builtin_fmaf(A, s1, B * s2));
+            m5 = __builtin_fmaf(Y00, m2 + Q, __builtin_fmaf(C, t1, D * t2));
+            m4 = __builtin_fmaf(X00, m2, __builtin_fmaf(Y00, P, __builtin_fmaf(A, t1, B * t2)));
           }
 #if MS_SCAN_STATS
           ++batch_chunks;

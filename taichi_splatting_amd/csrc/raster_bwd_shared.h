@@ -47,13 +47,13 @@ typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
 // ellipse-axis tests still apply); R = s * cutoff radius, i.e. |X'| - (|A'| + |B'|) h <= R on the ellipse axes.
 __device__ __forceinline__ void write_scan_record(const Raw& r, float alpha_threshold, float4* rec) {
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
-  const float isx = 1.0f / sx, isy = 1.0f / sy;
+  const float isx = rcp_newton(sx), isy = rcp_newton(sy);        // staging arithmetic: see raster_common.h
   const float s = EXP2_BASIS_SCALE;
   rec[0] = make_float4(mx, my, ax * isx * s, ay * isx * s);
-  rec[1] = make_float4(-ay * isy * s, ax * isy * s, -log2f(alpha), r.f[0]);
-  const float gs = sqrtf(2.0f * logf(alpha / alpha_threshold)) * 1.001f;     // NaN below the threshold: culled
+  rec[1] = make_float4(-ay * isy * s, ax * isy * s, -fast_log2(alpha), r.f[0]);
+  const float gs = cutoff_radius(alpha, alpha_threshold) * 1.001f;           // NaN below the threshold: culled
   const float v1x = ax * sx * gs, v1y = ay * sx * gs, v2x = -ay * sy * gs, v2y = ax * sy * gs;
-  float ex = (sqrtf(v1x * v1x + v2x * v2x) + 0.01f) * 1.002f, ey = (sqrtf(v1y * v1y + v2y * v2y) + 0.01f) * 1.002f;
+  float ex = (fast_sqrt(v1x * v1x + v2x * v2x) + 0.01f) * 1.002f, ey = (fast_sqrt(v1y * v1y + v2y * v2y) + 0.01f) * 1.002f;
   ex = ex > 6.0e4f ? __builtin_inff() : ex;      // cvt_pkrtz rounds toward zero: pre-inflated by 2^-9
   ey = ey > 6.0e4f ? __builtin_inff() : ey;
   const half2_t e = __builtin_amdgcn_cvt_pkrtz(ex, ey);

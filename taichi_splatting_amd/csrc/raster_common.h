@@ -66,6 +66,35 @@ __device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const 
   return r;
 }
 
+// Staging arithmetic (once per (tile, splat) overlap and kernel: ~250 instructions per staged splat with the
+// correctly rounded division / sqrtf / logf sequences of -fno-fast-math, 6 % of the backward's VALU instructions).
+// The hardware forms are within 1 ulp: v_rcp_f32 with one Newton step for the basis (0.5-1 ulp, the basis enters
+// every alpha), plain v_rcp_f32 / v_sqrt_f32 / v_log_f32 for the cull data, whose margins (x 1.001, + 0.01 px,
+// x 1.002) are four orders of magnitude wider.
+#ifndef MS_SLOW_STAGING
+#define MS_SLOW_STAGING 0            // 1: the library forms (A/B builds, tools/build_variant.sh)
+#endif
+#if MS_SLOW_STAGING
+__device__ __forceinline__ float rcp_newton(float x) { return 1.0f / x; }
+__device__ __forceinline__ float stage_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float fast_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return log2f(x); }
+#else
+__device__ __forceinline__ float rcp_newton(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+}
+__device__ __forceinline__ float stage_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+#endif
+// cutoff radius of the contribution region alpha g > threshold in units of sigma: sqrt(2 ln(alpha / threshold)),
+// NaN when alpha < threshold (every comparison of the hit tests then fails: culled)
+__device__ __forceinline__ float cutoff_radius(float alpha, float alpha_threshold) {
+  constexpr float TWO_LN2 = 1.38629436111989061883f;
+  return fast_sqrt(TWO_LN2 * (fast_log2(alpha) - fast_log2(alpha_threshold)));
+}
+
 constexpr float EXP2_SCALE = -0.72134752044448170368f;   // -0.5 * log2(e)
 constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2(e))
 
@@ -83,7 +112,7 @@ __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshol
                                               float origin_x = 0.0f, float origin_y = 0.0f) {
   const float basis_scale = FWD_FORM ? EXP2_BASIS_SCALE : 1.0f;
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
-  const float isx = 1.0f / sx, isy = 1.0f / sy;
+  const float isx = rcp_newton(sx), isy = rcp_newton(sy);
   const float A = ax * isx, B = ay * isx, C = -ay * isy, D = ax * isy;
   if (FWD_FORM) {
     const float rx = mx - origin_x, ry = my - origin_y;
@@ -91,14 +120,14 @@ __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshol
   } else {
     rec[0] = make_float4(mx, my, A, B);
   }
-  rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -log2f(alpha) : alpha, r.f[0]);
+  rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -fast_log2(alpha) : alpha, r.f[0]);
   rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
   // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
   // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
-  const float gs = sqrtf(2.0f * logf(alpha / alpha_threshold)) * 1.001f;
+  const float gs = cutoff_radius(alpha, alpha_threshold) * 1.001f;
   const float v1x = ax * sx * gs, v1y = ay * sx * gs, v2x = -ay * sy * gs, v2y = ax * sy * gs;
-  cull[0] = make_float4(mx, my, sqrtf(v1x * v1x + v2x * v2x) + 0.01f, sqrtf(v1y * v1y + v2y * v2y) + 0.01f);
-  const float igs = 1.0f / gs;
+  cull[0] = make_float4(mx, my, fast_sqrt(v1x * v1x + v2x * v2x) + 0.01f, fast_sqrt(v1y * v1y + v2y * v2y) + 0.01f);
+  const float igs = stage_rcp(gs);
   cull[1] = make_float4(A * igs, B * igs, C * igs, D * igs);
 }
 
