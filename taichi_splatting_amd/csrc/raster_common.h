@@ -82,7 +82,8 @@ __device__ __forceinline__ float fast_log2(float x) { return log2f(x); }
 #else
 __device__ __forceinline__ float rcp_newton(float x) {
   const float r = __builtin_amdgcn_rcpf(x);
-  return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+  const float e = __builtin_fmaf(-x, r, 1.0f);          // NaN for x = 0 / inf (r = inf / 0): the step is skipped
+  return fabsf(e) < 0.5f ? __builtin_fmaf(r, e, r) : r;
 }
 __device__ __forceinline__ float stage_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
