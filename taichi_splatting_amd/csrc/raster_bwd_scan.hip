@@ -115,7 +115,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
   constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : MS_T8_CAP;
   constexpr int NACC = HEUR ? 11 : 9;
-  constexpr bool GRID_MOMENTS = !HEUR && MS_GRID_MOMENTS != 0;   // see the blend loop
+  constexpr bool GRID_MOMENTS = MS_GRID_MOMENTS != 0;            // see the blend loop
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and PRIMARY + t)
   constexpr int PRIMARY = THREADS < BATCH ? THREADS : BATCH;      // slots filled by "thread t stages slot t"
   constexpr int SLOTS_B = PIPELINED ? BATCH - PRIMARY : 0;  // second slot of the first SLOTS_B threads
@@ -327,13 +327,17 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
           float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
           float h0 = 0.f, h1 = 0.f;
-          // GRID_MOMENTS (no heuristics): the six moments are first taken in the sub-patch's own pixel grid,
+          // GRID_MOMENTS: the six moments are first taken in the sub-patch's own pixel grid,
           //   n = sum q {1, x, y, x^2, x y, y^2},  x, y in 0..3,
           // where x and y are compile-time constants of the unrolled steps: a pixel row keeps r = sum_x q {1, x, x^2}
           // (7 additions / FMAs for its four pixels), a row end folds r into n with the constants y, y^2 (3 to 6), and
           // the chunk ends with the affine change of variables X = X00 + A x + B y, Y = Y00 + C x + D y (26) — 75
           // instructions per chunk instead of 16 x 8.
           float n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f, n4 = 0.f, n5 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+          // heuristics: |d mu| = |q (X A + Y C)| + |q (X B + Y D)| (backward.py:190-194) is affine in the grid too:
+          //   X A + Y C = gx0 + x gxx + y gxy,   X B + Y D = gy0 + x gxy + y gyy
+          const float gxx = __builtin_fmaf(A, A, C * C), gxy = __builtin_fmaf(A, B, C * D), gyy = __builtin_fmaf(B, B, D * D);
+          const float gx0 = __builtin_fmaf(X00, A, Y00 * C), gy0 = __builtin_fmaf(X00, B, Y00 * D);
 #if MS_SCAN_STATS
           int steps_run = 0, lanes_contrib = 0;
 #endif
@@ -418,8 +422,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
               const float q_ = ag * a_st[u];
               const float qX = q_ * X[u], qY = q_ * Y[u];
+              const int x = (i + u) & 3, y = i >> 2;                // compile-time in the unrolled loop
               if (GRID_MOMENTS) {
-                const int x = (i + u) & 3;                          // compile-time in the unrolled loop
                 r0 += q_;
                 if (x == 1) { r1 += q_; r2 += q_; }
                 if (x > 1) { r1 = __builtin_fmaf(q_, (float)x, r1); r2 = __builtin_fmaf(q_, (float)(x * x), r2); }
@@ -431,7 +435,13 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               if (HEUR) {                                           // backward.py:190-194
                 const float agm = a_st[u] != 0.0f ? ag : 0.0f;
                 h0 = __builtin_fmaf(agm, agm, h0);
-                h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+                if (GRID_MOMENTS) {
+                  const float bx = y == 0 ? gx0 : __builtin_fmaf(gxy, (float)y, gx0), by = y == 0 ? gy0 : __builtin_fmaf(gyy, (float)y, gy0);
+                  const float tx = x == 0 ? bx : __builtin_fmaf(gxx, (float)x, bx), ty = x == 0 ? by : __builtin_fmaf(gxy, (float)x, by);
+                  h1 += fabsf(q_ * tx) + fabsf(q_ * ty);
+                } else {
+                  h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+                }
               }
 #if MS_SCAN_STATS
               lanes_contrib += __builtin_popcountll(__ballot(w[u] != 0.0f));
