@@ -422,8 +422,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
               // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
               const float q_ = ag * a_st[u];
               const float qX = q_ * X[u], qY = q_ * Y[u];
-              const int x = (i + u) & 3, y = i >> 2;                // compile-time in the unrolled loop
               if (GRID_MOMENTS) {
+                const int x = (i + u) & 3;                          // compile-time in the unrolled loop
                 r0 += q_;
                 if (x == 1) { r1 += q_; r2 += q_; }
                 if (x > 1) { r1 = __builtin_fmaf(q_, (float)x, r1); r2 = __builtin_fmaf(q_, (float)(x * x), r2); }
@@ -436,6 +436,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                 const float agm = a_st[u] != 0.0f ? ag : 0.0f;
                 h0 = __builtin_fmaf(agm, agm, h0);
                 if (GRID_MOMENTS) {
+                  const int x = (i + u) & 3, y = i >> 2;
                   const float bx = y == 0 ? gx0 : __builtin_fmaf(gxy, (float)y, gx0), by = y == 0 ? gy0 : __builtin_fmaf(gyy, (float)y, gy0);
                   const float tx = x == 0 ? bx : __builtin_fmaf(gxx, (float)x, bx), ty = x == 0 ? by : __builtin_fmaf(gxy, (float)x, by);
                   h1 += fabsf(q_ * tx) + fabsf(q_ * ty);
