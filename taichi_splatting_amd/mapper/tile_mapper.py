@@ -109,19 +109,26 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                                            ctypes.byref(nbytes), stream), "map_to_tiles")
       return cum, (int(cum[v].item()) if want_total else None)
 
-    # 1. overlap counts in storage order (a streaming pass), exclusive scan, total K (the one host sync of the mapper)
+    def checked(total):
+      if total < 0:
+        raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
+                            "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
+      return total
+
     counts = torch.empty((v,), dtype=torch.int32, device=device)
-    _lib.check(lib.ms_tile_count(points.data_ptr(), None, v, w_pad, h_pad, tile_size, config.alpha_threshold,
-                                 row_begin, row_end, counts.data_ptr(), None, stream), "map_to_tiles")
-    cum, total = exclusive_scan(counts, True)
-    if total < 0:
-      raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
-                          "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-    if total == 0:
-      return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
-    if method is None:
+    cum = total = None
+    if method is None and use_depth16:
       # 16 bit keys: the pre-sort is two passes over v pairs and the tile sort moves 4-byte keys — always cheaper
-      method = 'presort' if (use_depth16 or total > PRESORT_ABOVE * v) else 'direct'
+      method = 'presort'
+    if method != 'presort':
+      # 1. overlap counts in storage order (a streaming pass), exclusive scan, total K (the one host sync of the mapper)
+      _lib.check(lib.ms_tile_count(points.data_ptr(), None, v, w_pad, h_pad, tile_size, config.alpha_threshold,
+                                   row_begin, row_end, counts.data_ptr(), None, stream), "map_to_tiles")
+      cum, total = exclusive_scan(counts, True)
+      if checked(total) == 0:
+        return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
+      if method is None:
+        method = 'presort' if total > PRESORT_ABOVE * v else 'direct'      # presort: counted again below, in depth order
 
     if method == 'direct':
       # 2. keys tile << 32 | depth key (ndc / 16 bit quantisation fused) in storage order; 3. STABLE sort on the tile
@@ -159,7 +166,12 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
     _lib.check(lib.ms_tile_count(points.data_ptr(), order.data_ptr(), v, w_pad, h_pad, tile_size,
                                  config.alpha_threshold, row_begin, row_end, counts.data_ptr(),
                                  ordered.data_ptr(), stream), "map_to_tiles")
-    cum, _ = exclusive_scan(counts, False)
+    if total is None:                            # the pre-sort was asked for: this scan's total is the host sync
+      cum, total = exclusive_scan(counts, True)
+      if checked(total) == 0:
+        return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
+    else:
+      cum, _ = exclusive_scan(counts, False)
 
     # 4. emit (tile id, point) in depth order; 5. STABLE sort on the tile id bits only
     keys = torch.empty((total,), dtype=torch.int32, device=device)
