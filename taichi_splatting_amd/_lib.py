@@ -70,7 +70,7 @@ class FrameInputsC(ctypes.Structure):
   """``ms_frame_inputs``"""
   _fields_ = [(name, c_void_p) for name in (
     'position', 'log_scaling', 'rotation', 'alpha_logit', 'feature', 'T_camera_world', 'projection',
-    'points7', 'depth', 'colours')]
+    'points7', 'depth', 'colours', 'longest_run_host')]
 
 
 class FrameGradsC(ctypes.Structure):

@@ -115,6 +115,8 @@ frame_prepare_kernel(int32_t* __restrict__ counters, int32_t capacity, const T* 
     const bool ok = k >= 0 && k <= capacity;
     counters[1] = ok ? k : 0;
     counters[2] = ok ? 0 : 1;
+    counters[3] = 0;                 // longest run of the per-tile sort's one-workgroup path, and the ticket of its
+    counters[4] = 0;                 // workgroups (tile_sort.hip)
     if (cam_out) camera_position_solve(Tcw, cam_out);
   }
 }
@@ -318,7 +320,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
       sort_pairs_u64_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, 32, 32 + g.tile_bits,
                                 sk + L.tmp_k, s);
       MS_TRY(find_ranges_u64_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s));
-      tile_depth_sort_launch(ranges, g.num_tiles, keys_sorted, o2p, keys, s);
+      tile_depth_sort_launch(ranges, g.num_tiles, keys_sorted, o2p, keys, s, counters + 3, in->longest_run_host);
     }
   }
   MS_CHECK_LAUNCH();

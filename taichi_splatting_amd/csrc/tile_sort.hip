@@ -33,10 +33,14 @@ constexpr int TS_COST_LIMIT = 64;          // bucket path: at most this many com
 #define TS_LONG_R 20
 #endif
 
+constexpr int TS_PER_WAVE = 256;           // bounded path: entries a wave ranks per round of the workgroup
 struct TsShared {
   uint32_t red[2 * TS_WAVES];
   uint32_t hist[256];
 };
+// a run the per-tile kernels decline (keys piled up in few buckets) is left to the long-run kernel through this word
+// in the first scratch slot of the run; no key is all ones (tile ids are below 2^31)
+constexpr uint64_t TS_DECLINED = ~0ull;
 
 __device__ __forceinline__ uint32_t ts_wave_min(uint32_t v) {
 #pragma unroll
@@ -87,8 +91,9 @@ __device__ __forceinline__ uint32_t ts_block_exclusive(uint32_t v, uint32_t* red
 
 // ---- bounded path: LSD radix sort of one run by the whole workgroup, on global memory ------------------------------
 // srt[b .. b + n): tile << 32 | depth key; o2p[b .. b + n): point indices (ascending); alt: scratch of the same extent.
+// wcnt: TS_WAVES * 256 words of LDS (per-wave digit counters, then write positions)
 __device__ void tile_radix_sort_global(uint64_t* srt, int32_t* o2p, uint64_t* alt,
-                                       int64_t b, int n, TsShared& sh) {
+                                       int64_t b, int n, TsShared& sh, uint32_t* wcnt) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t kor = 0u, kand = 0xffffffffu;
   for (int i = t; i < n; i += TS_THREADS) {
@@ -122,27 +127,49 @@ __device__ void tile_radix_sort_global(uint64_t* srt, int32_t* o2p, uint64_t* al
     __syncthreads();
     sh.hist[t] = base;                                           // running write position of digit t
     __syncthreads();
-    for (int c = 0; c < n; c += TS_THREADS) {
-      const int i = c + t;
-      const bool valid = i < n;
-      const uint64_t p = valid ? src[b + i] : 0ull;
-      const uint32_t d = (uint32_t)(p >> shift) & 0xffu;
-      uint64_t peers = __ballot(valid);
+    // 1024 entries per round of the workgroup: every wave ranks its 256 entries (four groups of 64, in order) against
+    // its OWN digit counters — no workgroup barrier inside — then one thread per digit turns the four waves' counts
+    // into write positions, and the entries go out.  Stable: waves, groups and lanes are taken in entry order.
+    for (int c = 0; c < n; c += TS_WAVES * TS_PER_WAVE) {
+      for (int j = t; j < TS_WAVES * 256; j += TS_THREADS) wcnt[j] = 0u;
+      __syncthreads();
+      uint64_t p[TS_PER_WAVE / 64];
+      uint32_t rank[TS_PER_WAVE / 64];
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool one = (d >> bit) & 1u;
-        const uint64_t bal = __ballot(one);
-        peers &= one ? bal : ~bal;
-      }
-      const uint64_t below = peers & ((1ull << lane) - 1ull);
-      for (int w = 0; w < TS_WAVES; ++w) {                       // waves take their turn: stable across the chunk
-        if (wave == w && valid) {
-          const uint32_t at = sh.hist[d];
-          dst[b + at + (uint32_t)__popcll(below)] = p;
-          if (below == 0ull) sh.hist[d] = at + (uint32_t)__popcll(peers);
+      for (int g = 0; g < TS_PER_WAVE / 64; ++g) {
+        const int i = c + wave * TS_PER_WAVE + g * 64 + lane;
+        const bool valid = i < n;
+        p[g] = valid ? src[b + i] : 0ull;
+        const uint32_t d = (uint32_t)(p[g] >> shift) & 0xffu;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+          const bool one = (d >> bit) & 1u;
+          const uint64_t bal = __ballot(one);
+          peers &= one ? bal : ~bal;
         }
-        __syncthreads();
+        const uint64_t below = peers & ((1ull << lane) - 1ull);
+        uint32_t prev = 0u;
+        if (valid) prev = wcnt[wave * 256 + d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0ull) wcnt[wave * 256 + d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[g] = prev + (uint32_t)__popcll(below);
       }
+      __syncthreads();
+      {
+        uint32_t at = sh.hist[t];                                 // thread t = digit t
+#pragma unroll
+        for (int w = 0; w < TS_WAVES; ++w) { const uint32_t cw = wcnt[w * 256 + t]; wcnt[w * 256 + t] = at; at += cw; }
+        sh.hist[t] = at;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < TS_PER_WAVE / 64; ++g) {
+        const int i = c + wave * TS_PER_WAVE + g * 64 + lane;
+        if (i < n) dst[b + wcnt[wave * 256 + ((uint32_t)(p[g] >> shift) & 0xffu)] + rank[g]] = p[g];
+      }
+      __syncthreads();
     }
     uint64_t* const swap = src; src = dst; dst = swap;
   }
@@ -163,8 +190,9 @@ struct BucketMap {
   }
 };
 
+// false: declined (nothing written) — the keys pile up in few buckets and the run belongs to the bounded path
 template <int R>
-__device__ __forceinline__ void tile_bucket_sort(uint64_t* __restrict__ srt, int32_t* __restrict__ o2p, uint64_t* __restrict__ alt,
+__device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
                                                  int64_t b, int n, uint64_t* pairs, uint32_t* cnt, TsShared& sh) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   uint32_t key[R], id[R];
@@ -189,7 +217,7 @@ __device__ __forceinline__ void tile_bucket_sort(uint64_t* __restrict__ srt, int
     kmin = sh.red[w] < kmin ? sh.red[w] : kmin;
     kmax = sh.red[TS_WAVES + w] > kmax ? sh.red[TS_WAVES + w] : kmax;
   }
-  if (kmin == kmax) return;                // one depth key: the run is in point order already
+  if (kmin == kmax) return true;           // one depth key: the run is in point order already
 
   const uint32_t nb = (uint32_t)n;
   BucketMap bucket;
@@ -230,11 +258,7 @@ __device__ __forceinline__ void tile_bucket_sort(uint64_t* __restrict__ srt, int
     if (w < wave) run += sh.red[w];
     cost += sh.red[TS_WAVES + w];
   }
-  if (cost > (uint32_t)TS_COST_LIMIT * nb) {             // keys pile up: take the bounded path (nothing written yet)
-    __syncthreads();
-    tile_radix_sort_global(srt, o2p, alt, b, n, sh);
-    return;
-  }
+  if (cost > (uint32_t)TS_COST_LIMIT * nb) return false;  // keys pile up (nothing written yet)
   for (uint32_t j = j0; j < j1; ++j) { const uint32_t c = cnt[j]; cnt[j] = run; run += c; }
   __syncthreads();
 
@@ -255,9 +279,11 @@ __device__ __forceinline__ void tile_bucket_sort(uint64_t* __restrict__ srt, int
       o2p[b + rank] = (int32_t)(uint32_t)p;
     }
   }
+  return true;
 }
 
-// One workgroup per tile (runs of lo < n <= hi <= 256 * R entries; the others belong to the kernel below).
+// One workgroup per tile (runs of lo < n <= hi <= 256 * R entries; the others belong to the kernel below).  Leaves
+// alt[b] = TS_DECLINED for a run it does not sort, 0 otherwise.
 template <int R>
 __global__ void __launch_bounds__(TS_THREADS)
 tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
@@ -270,16 +296,20 @@ tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict_
   const int64_t b = ranges[2 * tile];
   const int n = ranges[2 * tile + 1] - (int32_t)b;
   if (n <= lo || n > hi) return;           // lo >= 1: a single entry is sorted
-  tile_bucket_sort<R>(srt, o2p, alt, b, n, pairs, cnt, sh);
+  const bool sorted = tile_bucket_sort<R>(srt, o2p, b, n, pairs, cnt, sh);
+  if (threadIdx.x == 0) alt[b] = sorted ? 0ull : TS_DECLINED;
 }
 
-// The long runs (n > lo): 60 KB of LDS per workgroup, so the grid is a few workgroups per CU and each takes a
-// contiguous share of the tiles — one thread looks at one tile's length, the workgroup then sorts the ones that qualify.
+// The long runs (n > lo) and the declined ones: 60 KB of LDS per workgroup, so the grid is a few workgroups per CU and
+// each takes a contiguous share of the tiles — one thread looks at one tile's run, the workgroup then sorts the ones
+// that are its business: in LDS up to 256 * R entries, by the bounded path beyond (or when declined).
 template <int R>
 __global__ void __launch_bounds__(TS_THREADS)
 tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tiles, uint64_t* __restrict__ srt,
-                            int32_t* __restrict__ o2p, uint64_t* __restrict__ alt, int lo) {
+                            int32_t* __restrict__ o2p, uint64_t* __restrict__ alt, int lo, int32_t* __restrict__ run_stats,
+                            int32_t* __restrict__ run_host) {
   constexpr int CAP = TS_THREADS * R;
+  static_assert(CAP >= TS_WAVES * 256, "the bucket counters double as the bounded path's digit counters");
   __shared__ uint64_t pairs[CAP];
   __shared__ uint32_t cnt[CAP];
   __shared__ TsShared sh;
@@ -293,22 +323,40 @@ tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tile
     if (threadIdx.x == 0) todo_count = 0;
     __syncthreads();
     const int64_t mine = base + threadIdx.x;
-    if (mine < last && ranges[2 * mine + 1] - ranges[2 * mine] > lo) todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base);
+    if (mine < last) {
+      const int64_t mb = ranges[2 * mine];
+      const int mn = ranges[2 * mine + 1] - (int32_t)mb;
+      // bit 30 of the entry: declined by a per-tile kernel
+      if (mn > lo) {
+        todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base);
+        if (mn > CAP && run_stats) atomicMax(run_stats, mn);        // sorted by one workgroup through global memory
+      }
+      else if (mn > 1 && alt[mb] == TS_DECLINED) todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base) | (1 << 30);
+    }
     __syncthreads();
     const int count = todo_count;
     for (int j = 0; j < count; ++j) {
-      const int64_t tile = base + todo[j];
+      const int entry = todo[j];
+      const int64_t tile = base + (entry & 0xffff);
       const int64_t b = ranges[2 * tile];
       const int n = ranges[2 * tile + 1] - (int32_t)b;
-      if (n > CAP) tile_radix_sort_global(srt, o2p, alt, b, n, sh);
-      else tile_bucket_sort<R>(srt, o2p, alt, b, n, pairs, cnt, sh);
+      bool sorted = false;
+      if (n <= CAP && !(entry >> 30)) sorted = tile_bucket_sort<R>(srt, o2p, b, n, pairs, cnt, sh);
+      if (!sorted) {
+        __syncthreads();
+        tile_radix_sort_global(srt, o2p, alt, b, n, sh, cnt);
+      }
       __syncthreads();                     // done with the shared arrays before the next run
     }
+  }
+  if (run_stats && threadIdx.x == 0) {     // the last workgroup hands the longest run to the host
+    __threadfence();
+    if (atomicAdd(run_stats + 1, 1) == (int32_t)gridDim.x - 1 && run_host) *run_host = atomicMax(run_stats, 0);
   }
 }
 
 void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
-                            uint64_t* scratch, hipStream_t s) {
+                            uint64_t* scratch, hipStream_t s, int32_t* run_stats, int32_t* run_host) {
   if (num_tiles <= 0) return;
   const dim3 per_tile((unsigned)num_tiles), block(TS_THREADS);
   int covered = TS_THREADS * TS_SMALL_R;
@@ -320,7 +368,7 @@ void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint6
 #endif
   const int64_t few = 2 * 256;             // two workgroups of the long-run kernel fit a CU
   tile_depth_sort_long_kernel<TS_LONG_R><<<dim3((unsigned)(num_tiles < few ? num_tiles : few)), block, 0, s>>>(
-      tile_ranges, num_tiles, sorted_keys, overlap_to_point, scratch, covered);
+      tile_ranges, num_tiles, sorted_keys, overlap_to_point, scratch, covered, run_stats, run_host);
 }
 
 }  // namespace ms

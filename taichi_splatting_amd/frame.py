@@ -46,6 +46,12 @@ _mapper_mode = {}         # scene-shape key -> _lib.MAPPER_DIRECT / MAPPER_PRESO
 # direct - presort per frame: K/N 2.13 (config D) -0.16 ms, 2.25 (1 M, tile 32) -0.06, 2.59 (3 M) -0.08, 3.34 (1.5 M)
 # -0.04, 3.65 (config D at tile 8) +0.06 (tools/diag/ab_mapper.sh)
 PRESORT_ABOVE, DIRECT_BELOW = 3.6, 3.4
+# The direct sequence sorts a tile run beyond 5120 entries with ONE workgroup (~12 ns per entry: 0.25 ms at 20 000).  The
+# kernel leaves the longest such run of a frame in a pinned word (ms_frame_inputs.longest_run_host); a scene shape that
+# shows one above this limit maps with the pre-sort from the next frame on, whatever its overlaps per gaussian.
+LONG_RUN_LIMIT = 20000
+_run_words = {}           # scene-shape key -> (pinned int32[1] tensor, numpy view)
+_presort_sticky = set()   # scene shapes that showed a run above LONG_RUN_LIMIT
 _k_host = {}              # device index -> KSlots: a ring of pinned int32 words, ONE PER FRAME IN FLIGHT
 _moments = collections.OrderedDict()   # (device index, stream, n, deterministic) -> accumulator rows, zero between frames
 _moments_pinned = set()   # keys whose buffer address is baked into a captured HIP graph: never evicted
@@ -99,7 +105,7 @@ def _choose_mapper(key, k_total: int, n: int):
   4-byte pairs through the tile sort (1 M gaussians, K / n 2.45: 0.148 ms against 0.185)."""
   ratio = k_total / max(n, 1)
   now = _mapper_mode.get(key, _lib.MAPPER_DIRECT)
-  if key and key[-1] is True:
+  if (key and key[-1] is True) or key in _presort_sticky:
     now = _lib.MAPPER_PRESORT
   elif ratio > PRESORT_ABOVE:
     now = _lib.MAPPER_PRESORT
@@ -240,6 +246,9 @@ def release_caches(force: bool = False):
     _identity.clear()
     _k_capacity.clear()
     _mapper_mode.clear()
+    _presort_sticky.clear()
+    if force or not _captured_frames:
+      _run_words.clear()       # a captured frame writes its word at every replay
     if force:
       _k_host.clear()          # captured graphs write their overlap totals into these pinned words
 
@@ -369,6 +378,16 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   stream = _lib.current_stream(device)
   capturing = torch.cuda.is_current_stream_capturing()
   capacity = _k_capacity.get(key, 0)
+  # what the per-tile sort of an earlier frame of this shape reported (no synchronisation: the word is a frame or two old)
+  run_word = _run_words.get(key)
+  if run_word is None and not capturing:
+    t = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    run_word = _run_words[key] = (t, t.numpy())
+  if run_word is not None:
+    if int(run_word[1][0]) > LONG_RUN_LIMIT and key not in _presort_sticky:
+      _presort_sticky.add(key)
+      _mapper_mode[key] = _lib.MAPPER_PRESORT
+    inputs.longest_run_host = run_word[0].data_ptr()
   # the same in every call of this frame; before the first frame of a shape only the key width is known
   desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
   if capturing and capacity == 0:

@@ -223,3 +223,32 @@ def test_both_launch_sequences_give_the_same_lists_and_the_policy_switches():
   finally:
     frame.PRESORT_ABOVE, frame.DIRECT_BELOW = keep
     frame.release_caches()
+
+
+def test_a_giant_run_moves_the_scene_shape_to_the_presort_sequence():
+  # 60 000 small splats inside ONE tile: the direct sequence sorts that run with one workgroup and reports its length
+  # through a pinned word; frame.py then maps the shape with the pre-sort, whose cost does not depend on the spread
+  torch.manual_seed(31)
+  size, n = (256, 256), 60000
+  g = random_2d_gaussians(n, size, scale_factor=0.2, alpha_range=(0.3, 0.9))
+  g.position[:] = 84.0 + 6.0 * torch.rand(n, 2)                      # all inside tile (5, 5) of the 16 px grid
+  g.log_scaling[:] = torch.log(torch.full((n, 2), 0.4))
+  p, depth = project_gaussians2d(g).to(DEV), g.depths.reshape(-1).to(DEV)
+  features = torch.rand(n, 3, device=DEV)
+  cfg = RasterConfig(tile_size=16)
+  want_o2p, want_ranges = map_to_tiles(p, depth.reshape(-1, 1), size, cfg, method='presort')
+  assert int((want_ranges[..., 1] - want_ranges[..., 0]).max()) > frame.LONG_RUN_LIMIT
+  frame.release_caches()
+  try:
+    modes = []
+    for _ in range(3):
+      state = frame.FrameState()
+      frame._RasterizeFrameFunction.apply(p, depth, features, size, cfg, False, state)
+      state.settle()
+      torch.cuda.synchronize()                                       # the word of this frame is written
+      modes.append(int(state.desc.mapper))
+      k = int(state.counters()[0])
+      assert torch.equal(state.tile_ranges(), want_ranges) and torch.equal(state.overlap_to_point()[:k], want_o2p)
+    assert modes == [0, 1, 1]
+  finally:
+    frame.release_caches()
