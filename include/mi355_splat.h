@@ -319,10 +319,11 @@ typedef struct ms_frame_layout {
 typedef struct ms_frame_inputs {
   const void *position, *log_scaling, *rotation, *alpha_logit, *feature, *T_camera_world, *projection;
   const void *points7, *depth, *colours;       /* projected_input */
-  /* MS_MAPPER_DIRECT, optional (pinned host int32, device-visible): ms_frame_map_raster leaves there the length of the
-   * longest tile run beyond the per-tile sort's LDS classes (0: none).  Such a run is sorted by ONE workgroup at
-   * ~12 ns per entry — a caller that sees tens of thousands switches the scene shape to MS_MAPPER_PRESORT, whose cost
-   * does not depend on how the overlaps are spread over the tiles (taichi_splatting_amd/frame.py does). */
+  /* MS_MAPPER_DIRECT, optional (pinned host int32, device-visible): when a tile's run exceeds 16384 entries,
+   * ms_frame_map_raster writes its length there (one of them if there are several; never written otherwise).  Such a
+   * run is sorted by ONE workgroup at ~12 ns per entry — a caller that finds the word set switches the scene shape to
+   * MS_MAPPER_PRESORT, whose cost does not depend on how the overlaps are spread over the tiles
+   * (taichi_splatting_amd/frame.py does). */
   int32_t* longest_run_host;
 } ms_frame_inputs;
 

@@ -116,7 +116,8 @@ frame_prepare_kernel(int32_t* __restrict__ counters, int32_t capacity, const T* 
     counters[1] = ok ? k : 0;
     counters[2] = ok ? 0 : 1;
     counters[3] = 0;                 // longest run of the per-tile sort's one-workgroup path, and the ticket of its
-    counters[4] = 0;                 // workgroups (tile_sort.hip)
+    counters[4] = 0;                 // workgroups, "a run was declined" (tile_sort.hip)
+    counters[5] = 0;
     if (cam_out) camera_position_solve(Tcw, cam_out);
   }
 }

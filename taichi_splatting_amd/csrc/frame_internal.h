@@ -91,8 +91,9 @@ void tile_emit_direct_launch(const float* points7, const void* depth, int dtype,
 // Sorts every tile's run of `sorted_keys` (tile << 32 | depth key, already grouped by tile with the point indices in
 // `overlap_to_point` ascending inside each run) by (depth key, point index); only overlap_to_point is rewritten.
 // `scratch`: K u64 words the large-tile path may use (the unsorted key buffer is free by then).
-// run_stats (device, two zeroed words, or NULL): [0] <- length of the longest run beyond the LDS classes, [1] = ticket
-// of the workgroups; the last one copies [0] to *run_host (pinned, may be NULL).
+// run_stats (device, three zeroed words, or NULL): [2] = "a per-tile kernel declined a run" (NULL: the long-run kernel
+// reads every run's mark; [0], [1] unused).  run_host (pinned, may be NULL) receives the length of a run above 16384
+// entries if there is one.
 void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
                             uint64_t* scratch, hipStream_t s, int32_t* run_stats = nullptr, int32_t* run_host = nullptr);
 

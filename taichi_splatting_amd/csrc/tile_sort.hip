@@ -41,6 +41,7 @@ struct TsShared {
 // a run the per-tile kernels decline (keys piled up in few buckets) is left to the long-run kernel through this word
 // in the first scratch slot of the run; no key is all ones (tile ids are below 2^31)
 constexpr uint64_t TS_DECLINED = ~0ull;
+constexpr int TS_REPORT_ABOVE = 16384;      // runs longer than this are reported through ms_frame_inputs.longest_run_host
 
 __device__ __forceinline__ uint32_t ts_wave_min(uint32_t v) {
 #pragma unroll
@@ -287,7 +288,7 @@ __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int
 template <int R>
 __global__ void __launch_bounds__(TS_THREADS)
 tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
-                       uint64_t* __restrict__ alt, int lo, int hi) {
+                       uint64_t* __restrict__ alt, int lo, int hi, int32_t* __restrict__ run_stats) {
   constexpr int CAP = TS_THREADS * R;
   __shared__ uint64_t pairs[CAP];          // key << 32 | point index, grouped by bucket
   __shared__ uint32_t cnt[CAP];            // bucket sizes, then bucket offsets
@@ -297,7 +298,10 @@ tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict_
   const int n = ranges[2 * tile + 1] - (int32_t)b;
   if (n <= lo || n > hi) return;           // lo >= 1: a single entry is sorted
   const bool sorted = tile_bucket_sort<R>(srt, o2p, b, n, pairs, cnt, sh);
-  if (threadIdx.x == 0) alt[b] = sorted ? 0ull : TS_DECLINED;
+  if (threadIdx.x == 0) {
+    alt[b] = sorted ? 0ull : TS_DECLINED;
+    if (!sorted && run_stats) atomicOr(run_stats + 2, 1);          // tells the long-run kernel to look for the marks
+  }
 }
 
 // The long runs (n > lo) and the declined ones: 60 KB of LDS per workgroup, so the grid is a few workgroups per CU and
@@ -318,6 +322,7 @@ tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tile
   const int64_t share = (num_tiles + gridDim.x - 1) / gridDim.x;
   const int64_t first = (int64_t)blockIdx.x * share;
   const int64_t last = first + share < num_tiles ? first + share : num_tiles;
+  const bool any_declined = run_stats ? run_stats[2] != 0 : true;   // without the flag word every mark is read
   for (int64_t base = first; base < last; base += TS_THREADS) {
     __syncthreads();
     if (threadIdx.x == 0) todo_count = 0;
@@ -329,9 +334,10 @@ tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tile
       // bit 30 of the entry: declined by a per-tile kernel
       if (mn > lo) {
         todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base);
-        if (mn > CAP && run_stats) atomicMax(run_stats, mn);        // sorted by one workgroup through global memory
+        // a giant run (one workgroup, ~12 ns per entry) is reported to the host: any of them, if there are several
+        if (mn > TS_REPORT_ABOVE && run_host) *run_host = mn;
       }
-      else if (mn > 1 && alt[mb] == TS_DECLINED) todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base) | (1 << 30);
+      else if (any_declined && mn > 1 && alt[mb] == TS_DECLINED) todo[atomicAdd(&todo_count, 1)] = (int32_t)(mine - base) | (1 << 30);
     }
     __syncthreads();
     const int count = todo_count;
@@ -349,10 +355,6 @@ tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tile
       __syncthreads();                     // done with the shared arrays before the next run
     }
   }
-  if (run_stats && threadIdx.x == 0) {     // the last workgroup hands the longest run to the host
-    __threadfence();
-    if (atomicAdd(run_stats + 1, 1) == (int32_t)gridDim.x - 1 && run_host) *run_host = atomicMax(run_stats, 0);
-  }
 }
 
 void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
@@ -360,10 +362,11 @@ void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint6
   if (num_tiles <= 0) return;
   const dim3 per_tile((unsigned)num_tiles), block(TS_THREADS);
   int covered = TS_THREADS * TS_SMALL_R;
-  tile_depth_sort_kernel<TS_SMALL_R><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, 1, covered);
+  tile_depth_sort_kernel<TS_SMALL_R><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, 1, covered,
+                                                                run_stats);
 #if TS_MID_R > 0
   tile_depth_sort_kernel<TS_MID_R><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, covered,
-                                                             TS_THREADS * TS_MID_R);
+                                                             TS_THREADS * TS_MID_R, run_stats);
   covered = TS_THREADS * TS_MID_R;
 #endif
   const int64_t few = 2 * 256;             // two workgroups of the long-run kernel fit a CU

@@ -46,10 +46,10 @@ _mapper_mode = {}         # scene-shape key -> _lib.MAPPER_DIRECT / MAPPER_PRESO
 # direct - presort per frame: K/N 2.13 (config D) -0.16 ms, 2.25 (1 M, tile 32) -0.06, 2.59 (3 M) -0.08, 3.34 (1.5 M)
 # -0.04, 3.65 (config D at tile 8) +0.06 (tools/diag/ab_mapper.sh)
 PRESORT_ABOVE, DIRECT_BELOW = 3.6, 3.4
-# The direct sequence sorts a tile run beyond 5120 entries with ONE workgroup (~12 ns per entry: 0.25 ms at 20 000).  The
-# kernel leaves the longest such run of a frame in a pinned word (ms_frame_inputs.longest_run_host); a scene shape that
-# shows one above this limit maps with the pre-sort from the next frame on, whatever its overlaps per gaussian.
-LONG_RUN_LIMIT = 20000
+# The direct sequence sorts a tile run beyond 5120 entries with ONE workgroup (~12 ns per entry: 0.2 ms at 16 384).  The
+# kernel writes the length of a run above that size into a pinned word (ms_frame_inputs.longest_run_host); a scene
+# shape that shows one maps with the pre-sort from the next frame on, whatever its overlaps per gaussian.
+LONG_RUN_LIMIT = 16384
 _run_words = {}           # scene-shape key -> (pinned int32[1] tensor, numpy view)
 _presort_sticky = set()   # scene shapes that showed a run above LONG_RUN_LIMIT
 _k_host = {}              # device index -> KSlots: a ring of pinned int32 words, ONE PER FRAME IN FLIGHT

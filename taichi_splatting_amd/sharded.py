@@ -139,6 +139,11 @@ class _RankStep:
     self.flags = torch.zeros((2,), dtype=torch.int32).pin_memory()
     self.k_word = torch.zeros((1,), dtype=torch.int32).pin_memory()
     self._flags_np, self._k_np = self.flags.numpy(), self.k_word.numpy()
+    # the strip's mapper reports the longest tile run it sorted with a single workgroup; a strip that shows a giant one
+    # maps with the pre-sort sequence from the next step on (frame.LONG_RUN_LIMIT, same rule as render_gaussians)
+    self.run_word = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    self._run_np = self.run_word.numpy()
+    self.mapper = _lib.MAPPER_DIRECT
     self.strict = frame.STRICT
     self.last_counters = None    # counters view of the last strip frame
     self.comm_bytes = {}
@@ -147,6 +152,10 @@ class _RankStep:
     """mapper + raster forward of this rank's strip: returns (keep_n, keep_k, image (strip rows only), alpha)"""
     lib = _lib.load()
     stream = _lib.current_stream(device)
+    if int(self._run_np[0]) > frame.LONG_RUN_LIMIT:
+      self.mapper = _lib.MAPPER_PRESORT
+    desc.mapper = self.mapper
+    inputs.longest_run_host = self.run_word.data_ptr()
     lay = _layout(desc)
     keep_n, scratch_n = _block(lay.keep_n_bytes, device), _block(lay.scratch_n_bytes, device)
     keep_k, scratch_k = _block(lay.keep_k_bytes, device), _block(lay.scratch_k_bytes, device)
