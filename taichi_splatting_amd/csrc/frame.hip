@@ -1,12 +1,13 @@
-// frame.hip — the frame executor: one frame of the render path (project -> SH colour -> depth pre-sort -> overlap
-// count / scan / emit -> tile sort -> ranges -> raster forward; raster backward -> one per-gaussian backward pass) as
+// frame.hip — the frame executor: one frame of the render path (project -> SH colour -> overlap count / scan / emit
+// -> stable sort on the tile bits -> ranges -> per-tile depth sort [or: depth pre-sort -> count / scan / emit -> tile
+// sort -> ranges; ms_frame_desc.mapper] -> raster forward; raster backward -> one per-gaussian backward pass) as
 // a FIXED sequence of launches on one stream, with no host round trip in between (include/mi355_splat.h,
 // "frame executor").  The reference orchestrates the same stages from Python with two device synchronisations per
 // frame (the visible count in torch.nonzero, perspective/projection.py:147-150; the overlap total,
 // cuda_lib/full_cumsum.cu:45-46, mapper/tile_mapper.py:183-190); here neither count ever leaves the device:
 //
-//   * visible count: not needed — nothing is compacted.  A culled gaussian keeps its row, carries depth 0, gets the
-//     sort key CULLED_DEPTH_KEY, overlaps no tile and receives zero gradients;
+//   * visible count: not needed — nothing is compacted.  A culled gaussian keeps its row, carries depth 0 (and the
+//     sort key CULLED_DEPTH_KEY on the pre-sort sequence), overlaps no tile and receives zero gradients;
 //   * overlap total K: the kernels downstream of the scan read it from `counters` and run on capacity-sized grids.
 //
 // A caller may still LOOK at K (k_host / k_event) — after everything is enqueued — to grow its buffers.

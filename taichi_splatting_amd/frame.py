@@ -1,9 +1,10 @@
 """A whole frame as ONE autograd node on a fixed launch sequence (csrc/frame.hip, include/mi355_splat.h
 "frame executor").
 
-``render_gaussians`` (reference ``renderer.py:23-108``) runs through here: projection, SH colour, depth pre-sort,
-overlap count / scan / emission, tile sort, ranges and the raster forward are enqueued by two C calls, the backward
-pass by one (raster backward + ONE pass over the gaussians).  Differences to the reference's orchestration, none of
+``render_gaussians`` (reference ``renderer.py:23-108``) runs through here: projection, SH colour, the tile mapper
+(overlap count / scan / emission in storage order, stable sort on the tile bits, ranges, per-tile depth sort — or, per
+scene shape, the depth pre-sort sequence: ``_choose_mapper``) and the raster forward are enqueued by two C calls, the
+backward pass by one (raster backward + ONE pass over the gaussians).  Differences to the reference's orchestration, none of
 them visible in results:
 
 * nothing is compacted and the visible count V is never read back: culled gaussians keep their row (depth 0, no
