@@ -36,6 +36,8 @@
 // instructions, against ~126 per (8x8 patch, splat) hit of the pixel-per-lane kernel it replaces.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "raster_bwd_shared.h"
 #include "frame_internal.h"
 
@@ -116,6 +118,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : MS_T8_CAP;
   constexpr int NACC = HEUR ? 11 : 9;
   constexpr bool GRID_MOMENTS = MS_GRID_MOMENTS != 0;            // see the blend loop
+  // largest basis entry (A..D, in units of sqrt(log2 e / 2) / sigma per pixel) a chunk may hold and still use the grid
+  // form: 2.5 <=> sigma 0.34 px, where the expansion costs ~3e-5 of the moments' scale (fuzz: tools/fuzz_raster_bwd.py)
+  constexpr float GRID_MAX_BASIS = 2.5f;
   constexpr bool PIPELINED = THREADS >= 256;     // staged splats are gathered one batch ahead (slots t and PRIMARY + t)
   constexpr int PRIMARY = THREADS < BATCH ? THREADS : BATCH;      // slots filled by "thread t stages slot t"
   constexpr int SLOTS_B = PIPELINED ? BATCH - PRIMARY : 0;  // second slot of the first SLOTS_B threads
@@ -342,138 +347,155 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           int steps_run = 0, lanes_contrib = 0;
 #endif
 
-          // The 16 pixels are visited in PAIRS (x, x + 1 of one pixel row): the two pixels are independent, so each
-          // pair runs two dependency chains side by side.  The data of the next pair is requested before the
-          // current pair is evaluated.
-          constexpr int U = 2;                     // pixels per step (see wave_scan_mul2)
-          float4 pg[U];
-          float prg[U];
+          // Two instantiations of the 16 steps, chosen per chunk (wave-uniform): the grid form expands X, Y around the
+          // sub-patch's first pixel, where |X00| ~ 3.3 + 4 |A|: with a steep basis (sigma well below a pixel: only the
+          // 2D operators can hand those in, a projected gaussian has sigma >= sqrt(blur_cov) = 0.55 px) the products
+          // X00^2 n0, A^2 n3 ... cancel to the sum they stand for and lose digits the per-pixel form keeps.
+          auto blend_chunk = [&](auto grid_tag) {
+            constexpr bool GRID = decltype(grid_tag)::value;
+            // The 16 pixels are visited in PAIRS (x, x + 1 of one pixel row): the two pixels are independent, so each
+            // pair runs two dependency chains side by side.  The data of the next pair is requested before the
+            // current pair is evaluated.
+            constexpr int U = 2;                     // pixels per step (see wave_scan_mul2)
+            float4 pg[U];
+            float prg[U];
 #pragma unroll
-          for (int u = 0; u < U; ++u) { pg[u] = s_pix[wave][pbase + u]; prg[u] = s_rg[wave][pbase + u]; }
+            for (int u = 0; u < U; ++u) { pg[u] = s_pix[wave][pbase + u]; prg[u] = s_rg[wave][pbase + u]; }
 #pragma unroll
-          for (int i = 0; i < 16; i += U) {
-            const int p = pbase + i;
-            float4 cur[U];
-            float RGin[U];
-            bool any_alive = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              cur[u] = pg[u]; RGin[u] = prg[u];
-              any_alive |= __float_as_uint(cur[u].w) > oms_bits;
-              if (i + U < 16) { pg[u] = s_pix[wave][p + U + u]; prg[u] = s_rg[wave][p + U + u]; }
-            }
-            // wave-uniform: a group of saturated / out-of-image pixels is skipped; if only some of them are dead, their
-            // lanes all find T <= 1 - saturate_threshold below and contribute nothing
-            if (__ballot(any_alive) != 0) {
-
-            float X[U], Y[U], a_gated[U], a[U], om[U], Tk[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const int x = (i + u) & 3, y = i >> 2;
-              X[u] = x == 0 ? Xr[y] : __builtin_fmaf(A, (float)x, Xr[y]);
-              Y[u] = x == 0 ? Yr[y] : __builtin_fmaf(C, (float)x, Yr[y]);
-              const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X[u], X[u], __builtin_fmaf(Y[u], Y[u], nl2a)));
-              // blend gate (forward.py:99-101): lanes below the threshold carry alpha = 0 from here on
-              a_gated[u] = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
-              a[u] = min_f32_uniform(a_gated[u], rp.clamp_max_alpha);
-              om[u] = 1.0f - a[u];
-              // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)
-              Tk[u] = dpp_f32<0x138>(cur[u].w, om[u]);                              // wave_shr:1
-            }
-            wave_scan_mul2(Tk[0], Tk[1]);
-            // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
-            // A pixel crosses that line inside at most one chunk of its life: wave-uniform slow path.
-            float a_st[U];                                                          // straight-through alpha (below)
-            bool any_sat = false;
-#pragma unroll
-            for (int u = 0; u < U; ++u) { a_st[u] = a_gated[u]; any_sat |= !(Tk[u] > oms); }
-            if (__ballot(any_sat) != 0) {
-              asm volatile("; saturation inside the chunk" ::: "memory");          // keep this a branch, not selects
+            for (int i = 0; i < 16; i += U) {
+              const int p = pbase + i;
+              float4 cur[U];
+              float RGin[U];
+              bool any_alive = false;
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                const bool live = Tk[u] > oms;
-                a[u] = live ? a[u] : 0.0f;
-                a_st[u] = live ? a_gated[u] : 0.0f;
+                cur[u] = pg[u]; RGin[u] = prg[u];
+                any_alive |= __float_as_uint(cur[u].w) > oms_bits;
+                if (i + U < 16) { pg[u] = s_pix[wave][p + U + u]; prg[u] = s_rg[wave][p + U + u]; }
               }
-            }
-            float w[U], fG[U], S[U];
+              // wave-uniform: a group of saturated / out-of-image pixels is skipped; if only some of them are dead, their
+              // lanes all find T <= 1 - saturate_threshold below and contribute nothing
+              if (__ballot(any_alive) != 0) {
+
+              float X[U], Y[U], a_gated[U], a[U], om[U], Tk[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              w[u] = a[u] * Tk[u];
-              fG[u] = __builtin_fmaf(f2, cur[u].z, __builtin_fmaf(f1, cur[u].y, f0 * cur[u].x));
-              S[u] = w[u] * fG[u];
-            }
-            wave_scan_add2(S[0], S[1]);
-            // <R, G> after this splat: R -= f w  (backward.py:171-174)
-            float RGout[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) RGout[u] = RGin[u] - S[u];
-            // the last lane holds the state of both pixels after the whole chunk: one masked block, three LDS writes
-            if (last_lane) {
-              s_pix[wave][p].w = Tk[0] * om[0];
-              s_pix[wave][p + 1].w = Tk[1] * om[1];
-              *reinterpret_cast<float2*>(&s_rg[wave][p]) = make_float2(RGout[0], RGout[1]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const float RGk = RGout[u];
-              // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
-              const float ag = __builtin_fmaf(Tk[u], fG[u], -(RGk * __builtin_amdgcn_rcpf(om[u])));
-              // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
-              const float q_ = ag * a_st[u];
-              const float qX = q_ * X[u], qY = q_ * Y[u];
-              if (GRID_MOMENTS) {
-                const int x = (i + u) & 3;                          // compile-time in the unrolled loop
-                r0 += q_;
-                if (x == 1) { r1 += q_; r2 += q_; }
-                if (x > 1) { r1 = __builtin_fmaf(q_, (float)x, r1); r2 = __builtin_fmaf(q_, (float)(x * x), r2); }
-              } else {
-                m0 += q_; m1 += qX; m2 += qY;
-                m3 = __builtin_fmaf(qX, X[u], m3); m4 = __builtin_fmaf(qX, Y[u], m4); m5 = __builtin_fmaf(qY, Y[u], m5);
+              for (int u = 0; u < U; ++u) {
+                const int x = (i + u) & 3, y = i >> 2;
+                X[u] = x == 0 ? Xr[y] : __builtin_fmaf(A, (float)x, Xr[y]);
+                Y[u] = x == 0 ? Yr[y] : __builtin_fmaf(C, (float)x, Yr[y]);
+                const float a_raw = __builtin_amdgcn_exp2f(-__builtin_fmaf(X[u], X[u], __builtin_fmaf(Y[u], Y[u], nl2a)));
+                // blend gate (forward.py:99-101): lanes below the threshold carry alpha = 0 from here on
+                a_gated[u] = a_raw > rp.alpha_threshold ? a_raw : 0.0f;
+                a[u] = min_f32_uniform(a_gated[u], rp.clamp_max_alpha);
+                om[u] = 1.0f - a[u];
+                // T before this splat: exclusive prefix product seeded with the pixel's T (lane 0 <- T of the pixel)
+                Tk[u] = dpp_f32<0x138>(cur[u].w, om[u]);                              // wave_shr:1
               }
-              a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
-              if (HEUR) {                                           // backward.py:190-194
-                const float agm = a_st[u] != 0.0f ? ag : 0.0f;
-                h0 = __builtin_fmaf(agm, agm, h0);
-                if (GRID_MOMENTS) {
-                  const int x = (i + u) & 3, y = i >> 2;
-                  const float bx = y == 0 ? gx0 : __builtin_fmaf(gxy, (float)y, gx0), by = y == 0 ? gy0 : __builtin_fmaf(gyy, (float)y, gy0);
-                  const float tx = x == 0 ? bx : __builtin_fmaf(gxx, (float)x, bx), ty = x == 0 ? by : __builtin_fmaf(gxy, (float)x, by);
-                  h1 += fabsf(q_ * tx) + fabsf(q_ * ty);
-                } else {
-                  h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+              wave_scan_mul2(Tk[0], Tk[1]);
+              // saturation skip (backward.py:154): splats that find T <= 1 - saturate_threshold do not blend.
+              // A pixel crosses that line inside at most one chunk of its life: wave-uniform slow path.
+              float a_st[U];                                                          // straight-through alpha (below)
+              bool any_sat = false;
+#pragma unroll
+              for (int u = 0; u < U; ++u) { a_st[u] = a_gated[u]; any_sat |= !(Tk[u] > oms); }
+              if (__ballot(any_sat) != 0) {
+                asm volatile("; saturation inside the chunk" ::: "memory");          // keep this a branch, not selects
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  const bool live = Tk[u] > oms;
+                  a[u] = live ? a[u] : 0.0f;
+                  a_st[u] = live ? a_gated[u] : 0.0f;
                 }
               }
-#if MS_SCAN_STATS
-              lanes_contrib += __builtin_popcountll(__ballot(w[u] != 0.0f));
-#endif
-            }
-#if MS_SCAN_STATS
-            steps_run += U;
-#endif
-            }
-            if (GRID_MOMENTS && (i & 3) == 2) {                     // end of pixel row y: fold it into the grid moments
-              const int y = i >> 2;
-              n0 += r0; n1 += r1; n3 += r2;
-              if (y == 1) { n2 += r0; n4 += r1; n5 += r0; }
-              if (y > 1) {
-                n2 = __builtin_fmaf(r0, (float)y, n2); n4 = __builtin_fmaf(r1, (float)y, n4);
-                n5 = __builtin_fmaf(r0, (float)(y * y), n5);
+              float w[U], fG[U], S[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                w[u] = a[u] * Tk[u];
+                fG[u] = __builtin_fmaf(f2, cur[u].z, __builtin_fmaf(f1, cur[u].y, f0 * cur[u].x));
+                S[u] = w[u] * fG[u];
               }
-              r0 = 0.f; r1 = 0.f; r2 = 0.f;
+              wave_scan_add2(S[0], S[1]);
+              // <R, G> after this splat: R -= f w  (backward.py:171-174)
+              float RGout[U];
+#pragma unroll
+              for (int u = 0; u < U; ++u) RGout[u] = RGin[u] - S[u];
+              // the last lane holds the state of both pixels after the whole chunk: one masked block, three LDS writes
+              if (last_lane) {
+                s_pix[wave][p].w = Tk[0] * om[0];
+                s_pix[wave][p + 1].w = Tk[1] * om[1];
+                *reinterpret_cast<float2*>(&s_rg[wave][p]) = make_float2(RGout[0], RGout[1]);
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const float RGk = RGout[u];
+                // d(alpha) = T <f, G> - <R, G> / (1 - alpha)
+                const float ag = __builtin_fmaf(Tk[u], fG[u], -(RGk * __builtin_amdgcn_rcpf(om[u])));
+                // straight-through clamp (backward.py:158-163): d(alpha_pt g) = d(alpha); q = alpha_pt g d(alpha)
+                const float q_ = ag * a_st[u];
+                const float qX = q_ * X[u], qY = q_ * Y[u];
+                if (GRID) {
+                  const int x = (i + u) & 3;                          // compile-time in the unrolled loop
+                  r0 += q_;
+                  if (x == 1) { r1 += q_; r2 += q_; }
+                  if (x > 1) { r1 = __builtin_fmaf(q_, (float)x, r1); r2 = __builtin_fmaf(q_, (float)(x * x), r2); }
+                } else {
+                  m0 += q_; m1 += qX; m2 += qY;
+                  m3 = __builtin_fmaf(qX, X[u], m3); m4 = __builtin_fmaf(qX, Y[u], m4); m5 = __builtin_fmaf(qY, Y[u], m5);
+                }
+                a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
+                if (HEUR) {                                           // backward.py:190-194
+                  const float agm = a_st[u] != 0.0f ? ag : 0.0f;
+                  h0 = __builtin_fmaf(agm, agm, h0);
+                  if (GRID) {
+                    const int x = (i + u) & 3, y = i >> 2;
+                    const float bx = y == 0 ? gx0 : __builtin_fmaf(gxy, (float)y, gx0), by = y == 0 ? gy0 : __builtin_fmaf(gyy, (float)y, gy0);
+                    const float tx = x == 0 ? bx : __builtin_fmaf(gxx, (float)x, bx), ty = x == 0 ? by : __builtin_fmaf(gxy, (float)x, by);
+                    h1 += fabsf(q_ * tx) + fabsf(q_ * ty);
+                  } else {
+                    h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+                  }
+                }
+#if MS_SCAN_STATS
+                lanes_contrib += __builtin_popcountll(__ballot(w[u] != 0.0f));
+#endif
+              }
+#if MS_SCAN_STATS
+              steps_run += U;
+#endif
+              }
+              if (GRID && (i & 3) == 2) {                     // end of pixel row y: fold it into the grid moments
+                const int y = i >> 2;
+                n0 += r0; n1 += r1; n3 += r2;
+                if (y == 1) { n2 += r0; n4 += r1; n5 += r0; }
+                if (y > 1) {
+                  n2 = __builtin_fmaf(r0, (float)y, n2); n4 = __builtin_fmaf(r1, (float)y, n4);
+                  n5 = __builtin_fmaf(r0, (float)(y * y), n5);
+                }
+                r0 = 0.f; r1 = 0.f; r2 = 0.f;
+              }
             }
-          }
-          if (GRID_MOMENTS) {
-            // X = X00 + A x + B y,  Y = Y00 + C x + D y:  sums of q {1, X, Y, X^2, X Y, Y^2} from the grid moments
-            const float P = __builtin_fmaf(A, n1, B * n2), Q = __builtin_fmaf(C, n1, D * n2);
-            const float s1 = __builtin_fmaf(A, n3, B * n4), s2 = __builtin_fmaf(A, n4, B * n5);
-            const float t1 = __builtin_fmaf(C, n3, D * n4), t2 = __builtin_fmaf(C, n4, D * n5);
-            m0 = n0;
-            m1 = __builtin_fmaf(X00, n0, P);
-            m2 = __builtin_fmaf(Y00, n0, Q);
-            m3 = __builtin_fmaf(X00, m1 + P, __builtin_fmaf(A, s1, B * s2));
-            m5 = __builtin_fmaf(Y00, m2 + Q, __builtin_fmaf(C, t1, D * t2));
-            m4 = __builtin_fmaf(X00, m2, __builtin_fmaf(Y00, P, __builtin_fmaf(A, t1, B * t2)));
+            if (GRID) {
+              // X = X00 + A x + B y,  Y = Y00 + C x + D y:  sums of q {1, X, Y, X^2, X Y, Y^2} from the grid moments
+              const float P = __builtin_fmaf(A, n1, B * n2), Q = __builtin_fmaf(C, n1, D * n2);
+              const float s1 = __builtin_fmaf(A, n3, B * n4), s2 = __builtin_fmaf(A, n4, B * n5);
+              const float t1 = __builtin_fmaf(C, n3, D * n4), t2 = __builtin_fmaf(C, n4, D * n5);
+              m0 = n0;
+              m1 = __builtin_fmaf(X00, n0, P);
+              m2 = __builtin_fmaf(Y00, n0, Q);
+              m3 = __builtin_fmaf(X00, m1 + P, __builtin_fmaf(A, s1, B * s2));
+              m5 = __builtin_fmaf(Y00, m2 + Q, __builtin_fmaf(C, t1, D * t2));
+              m4 = __builtin_fmaf(X00, m2, __builtin_fmaf(Y00, P, __builtin_fmaf(A, t1, B * t2)));
+            }
+          };
+          {
+            const bool steep = fmaxf(fmaxf(fabsf(A), fabsf(B)), fmaxf(fabsf(C), fabsf(D))) > GRID_MAX_BASIS;
+#if MS_GRID_MOMENTS == 2               // A/B builds: the grid form whatever the basis
+            (void)steep;
+            blend_chunk(std::true_type{});
+#else
+            if (GRID_MOMENTS && __ballot(valid && steep) == 0) blend_chunk(std::true_type{});
+            else blend_chunk(std::false_type{});
+#endif
           }
 #if MS_SCAN_STATS
           ++batch_chunks;

@@ -296,6 +296,44 @@ def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale
     assert_within(got, want, 1e-4, what)
 
 
+@pytest.mark.parametrize('heuristics', [False, True])
+@pytest.mark.parametrize('tile_size', [8, 16])
+def test_sub_pixel_splats_keep_their_gradient_digits(tile_size, heuristics):
+  # splats far narrower than a pixel (the 2D operators accept any sigma): the backward's grid form of the moment sums
+  # would cancel catastrophically there (basis entries of tens per pixel) — the kernel switches those chunks to the
+  # per-pixel form.  Mixed with ordinary splats so that both forms run inside one tile.
+  torch.manual_seed(77 + tile_size)
+  size, n = (96, 80), 6000
+  cfg = cfg_for(tile_size, compute_point_heuristic=heuristics)
+  g = random_2d_gaussians(n, size, scale_factor=1.0, alpha_range=(0.3, 0.95))
+  tiny = torch.rand(n) < 0.5
+  g.log_scaling[tiny] = torch.log(0.01 + 0.15 * torch.rand(int(tiny.sum()), 2))          # sigma 0.01 .. 0.16 px
+  g.position[tiny] = (g.position[tiny].floor() + 0.5 + 0.02 * torch.randn(int(tiny.sum()), 2)).clamp(0.5, min(size) - 0.5)
+  g = gate_stable(g, size, cfg).to(DEV)
+  p32 = project_gaussians2d(g)
+  assert (p32[:, 4:6].min(dim=1).values < 0.2).float().mean() > 0.3
+  o2p, ranges = map_to_tiles(p32, g.depths, size, cfg)
+  ranges = ranges.view(-1, 2)
+  torch.manual_seed(2)
+  G = torch.randn(size[1], size[0], 3, device=DEV)
+  res = {}
+  for dtype in (torch.float64, torch.float32):
+    p = p32.to(dtype).clone().requires_grad_(True)
+    f = g.feature.to(dtype).clone().requires_grad_(True)
+    out = rasterize_with_tiles(p, f, o2p, ranges, size, cfg)
+    (out.image * G.to(dtype)).sum().backward()
+    res[dtype] = (p.grad.double(), f.grad.double(), out.point_heuristic.double())
+  gp64, gf64, h64 = res[torch.float64]
+  gp32, gf32, h32 = res[torch.float32]
+  assert gp64[:, 4:6].abs().max() > 0                       # the tiny splats do receive sigma gradients
+  # column by column: a sub-pixel splat's d sigma is orders of magnitude above its d mean
+  for k, name in enumerate(('mean.x', 'mean.y', 'axis.x', 'axis.y', 'sigma.x', 'sigma.y', 'alpha')):
+    assert_within(gp32[:, k], gp64[:, k], 1e-4, f"d gaussians2d[{name}]")
+  assert_within(gf32, gf64, 1e-4, 'd features')
+  if heuristics:
+    assert_within(h32, h64, 1e-4, 'heuristics')
+
+
 @pytest.mark.parametrize('tile_size,n,size,scale,alpha', [(16, 20000, (333, 200), 1.0, (0.1, 0.9)), (8, 6000, (96, 64), 5.0, (0.5, 1.0)),
                                                           (32, 100000, (640, 480), 1.5, (0.02, 0.9))])
 def test_f32_antialias_matches_f64(tile_size, n, size, scale, alpha):
