@@ -248,8 +248,12 @@ def release_caches(force: bool = False):
     _k_capacity.clear()
     _mapper_mode.clear()
     _presort_sticky.clear()
-    if force or not _captured_frames:
-      _run_words.clear()       # a captured frame writes its word at every replay
+    # the run words stay (4 pinned bytes per scene shape): a frame still in flight, or a captured one at every replay,
+    # writes its word — handing the memory back to the allocator would let that write land in somebody else's tensor
+    for _, view in _run_words.values():
+      view[0] = 0
+    if force:
+      _run_words.clear()
     if force:
       _k_host.clear()          # captured graphs write their overlap totals into these pinned words
 
