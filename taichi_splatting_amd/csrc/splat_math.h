@@ -124,17 +124,26 @@ MS_HD bool project_forward(const T p[3], const T ls[3], const T q[4], T alpha_lo
   st.b = st.M[0][0] * st.M[1][0] + st.M[0][1] * st.M[1][1] + st.M[0][2] * st.M[1][2];
   st.c = st.M[1][0] * st.M[1][0] + st.M[1][1] * st.M[1][1] + st.M[1][2] * st.M[1][2] + pp.blur_cov;
 
-  // eig: taichi_lib/generic.py:217-230
+  // eig: taichi_lib/generic.py:217-230 — the same eigen-pair, evaluated without the two cancellations of the
+  // reference's formula chain (round 5; the backward has used this form since round 4).  The reference takes
+  // sqrt(tr^2 - 4 det) and normalises (a - l2, b): for a >= c that vector adds two positive numbers, for a < c it is
+  // (a - c + sg) / 2 with sg ~ c - a, which in float32 loses the small component of a nearly vertical axis (torch_lib's
+  // own float32 arithmetic: axis off by 1e-2, the rebuilt covariance by 2.6e-3 on the test protocol).  Here a - c comes
+  // from the factors of M (the blur term drops out exactly), l1 - l2 = hypot(a - c, 2 b), and the eigenvector from
+  // whichever of (a - l2, b) and +-(b, l1 - a) — the same direction, first component >= 0 — adds two positive
+  // numbers.  float64 agrees with the reference fixtures to 1e-12.  a < c with b == 0 exactly gives the axis (0, 1)
+  // where the reference divides 0 by 0.
   st.tr = st.a + st.c;
-  const T det = st.a * st.c - st.b * st.b;
-  st.gap = st.tr * st.tr - 4 * det;
-  st.sg = t_sqrt(t_max(st.gap, T(0)));
+  T amc = T(0);                                   // a - c
+  for (int j = 0; j < 3; ++j) amc += (st.M[0][j] - st.M[1][j]) * (st.M[0][j] + st.M[1][j]);
+  st.sg = t_sqrt(amc * amc + 4 * st.b * st.b);
+  st.gap = st.sg * st.sg;
   st.l1 = (st.tr + st.sg) * T(0.5);
   st.l2 = (st.tr - st.sg) * T(0.5);
   st.sigma[0] = t_sqrt(st.l1);
   st.sigma[1] = t_sqrt(st.l2);
-  st.v[0] = st.a - st.l2;
-  st.v[1] = st.b;
+  if (amc >= 0) { st.v[0] = (amc + st.sg) * T(0.5); st.v[1] = st.b; }                                  // (a - l2, b)
+  else { st.v[0] = st.b < 0 ? -st.b : st.b; st.v[1] = (st.b < 0 ? T(-0.5) : T(0.5)) * (st.sg - amc); }  // +-(b, l1 - a)
   st.vn = t_sqrt(st.v[0] * st.v[0] + st.v[1] * st.v[1]);
   st.axis[0] = st.v[0] / st.vn;
   st.axis[1] = st.v[1] / st.vn;
@@ -188,16 +197,11 @@ MS_HD void project_backward(const T p[3], const Camera<T>& cam, const ProjState<
   // fixtures to 1e-12); what is left in float32 is the conditioning of the problem itself, eps * a / sg.
   const T dl1 = g_sigma[0] / (2 * st.sigma[0]);
   const T dl2 = g_sigma[1] / (2 * st.sigma[1]);
-  T amc = T(0);                                   // a - c
-  for (int j = 0; j < 3; ++j) amc += (st.M[0][j] - st.M[1][j]) * (st.M[0][j] + st.M[1][j]);
-  const T sg = t_sqrt(amc * amc + 4 * st.b * st.b);
-  T u0, u1;
-  if (amc >= 0) { u0 = (amc + sg) * T(0.5); u1 = st.b; }                              // (a - l2, b)
-  else { u0 = st.b < 0 ? -st.b : st.b; u1 = (st.b < 0 ? T(-0.5) : T(0.5)) * (sg - amc); }   // +-(b, l1 - a): same direction, u0 >= 0
-  const T un = t_sqrt(u0 * u0 + u1 * u1);
+  // (project_forward already holds the pair in this form: sg = hypot(a - c, 2 b), axis from the non-cancelling vector)
+  const T sg = st.sg, un = st.vn;
+  T u0 = st.axis[0], u1 = st.axis[1];
   T da, db, dc;
   if (st.gap > 0 && un > 0) {
-    u0 /= un; u1 /= un;
     const T kappa = (g_axis[1] * u0 - g_axis[0] * u1) / sg;      // <g_axis, w> / (l1 - l2), w = (-u1, u0)
     const T uu = u0 * u0, ww = u1 * u1, uw = u0 * u1;
     da = dl1 * uu + dl2 * ww - kappa * uw;

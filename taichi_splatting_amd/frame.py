@@ -306,10 +306,16 @@ def _moments_buffer(device, n: int, deterministic: bool) -> torch.Tensor:
 
 
 def _drop_moments():
-  """After a failed backward enqueue the accumulator rows may be half-written: start from fresh buffers."""
+  """After a failed backward enqueue the accumulator rows may be half-written: start from clean ones.  Buffers whose
+  address a captured HIP graph replays into are zeroed IN PLACE (freeing them would let the next replay accumulate into
+  memory the allocator has handed to someone else — what ``release_caches`` guards against with ``force``); the others
+  are dropped and reallocated on demand."""
   with _lock:
-    _moments.clear()
-    _moments_pinned.clear()
+    for key in list(_moments):
+      if key in _moments_pinned:
+        _moments[key].zero_()
+      else:
+        del _moments[key]
 
 
 class FrameState:
@@ -382,19 +388,22 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   lib = _lib.load()
   stream = _lib.current_stream(device)
   capturing = torch.cuda.is_current_stream_capturing()
-  capacity = _k_capacity.get(key, 0)
-  # what the per-tile sort of an earlier frame of this shape reported (no synchronisation: the word is a frame or two old)
-  run_word = _run_words.get(key)
-  if run_word is None and not capturing:
-    t = torch.zeros((1,), dtype=torch.int32).pin_memory()
-    run_word = _run_words[key] = (t, t.numpy())
-  if run_word is not None:
-    if int(run_word[1][0]) > LONG_RUN_LIMIT and key not in _presort_sticky:
-      _presort_sticky.add(key)
-      _mapper_mode[key] = _lib.MAPPER_PRESORT
-    inputs.longest_run_host = run_word[0].data_ptr()
-  # the same in every call of this frame; before the first frame of a shape only the key width is known
-  desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
+  # the scene-shape caches are shared by every thread that renders (a viewer next to a trainer): looked up and updated
+  # under the lock
+  with _lock:
+    capacity = _k_capacity.get(key, 0)
+    # what the per-tile sort of an earlier frame of this shape reported (no synchronisation: the word is a frame or two old)
+    run_word = _run_words.get(key)
+    if run_word is None and not capturing:
+      t = torch.zeros((1,), dtype=torch.int32).pin_memory()
+      run_word = _run_words[key] = (t, t.numpy())
+    if run_word is not None:
+      if int(run_word[1][0]) > LONG_RUN_LIMIT and key not in _presort_sticky:
+        _presort_sticky.add(key)
+        _mapper_mode[key] = _lib.MAPPER_PRESORT
+      inputs.longest_run_host = run_word[0].data_ptr()
+    # the same in every call of this frame; before the first frame of a shape only the key width is known
+    desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")
@@ -457,7 +466,11 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
 
   state.capacity = 0
   if capacity > 0:
-    map_raster(capacity)          # everything is enqueued before the host looks at K
+    try:
+      map_raster(capacity)        # everything is enqueued before the host looks at K
+    except Exception:
+      ring.release(slot)          # (an allocation failure here must not leave the frame's K word busy for ever)
+      raise
   if capacity == 0 or settle_now:
     settle()
   else:

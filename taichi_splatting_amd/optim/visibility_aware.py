@@ -24,6 +24,38 @@ def _track_visibility(running: torch.Tensor, seen: torch.Tensor, indexes: torch.
   return seen / torch.clamp_min(mixed, floor)
 
 
+# The reference's module-level helpers (optim/visibility_aware.py:11-52): same names, argument order and results, as
+# thin wrappers, so that ``from taichi_splatting.optim.visibility_aware import update_visibility`` keeps working.
+def get_running_vis(state: dict, n: int, device: torch.device) -> torch.Tensor:
+  return PointState(state).per_point('running_vis', n, device)
+
+
+def lerp(t, a, b):
+  """Value a fraction ``t`` of the way from ``a`` to ``b``."""
+  return torch.lerp(torch.as_tensor(a), torch.as_tensor(b), t) if torch.is_tensor(t) else a + t * (b - a)
+
+
+def max_decaying(t, a, b):
+  return torch.maximum(a, lerp(t, a, b))
+
+
+def power_lerp(t, a, b, k=2):
+  """Interpolation of the k-th powers, back at the first power: a power mean of the end points."""
+  return lerp(t, a ** k, b ** k) ** (1 / k)
+
+
+def update_visibility(running_vis: torch.Tensor, visibility: torch.Tensor, indexes: torch.Tensor,
+                      total_weight: Optional[torch.Tensor] = None, beta: float = 0.9, eps: float = 1e-12) -> torch.Tensor:
+  """Updates ``running_vis[indexes]`` in place and returns the step weights (``total_weight`` is unused, as in the
+  reference)."""
+  return _track_visibility(running_vis, visibility, indexes, beta, floor=eps)
+
+
+def set_indexes(target: torch.Tensor, values: torch.Tensor, indexes: torch.Tensor) -> torch.Tensor:
+  """A zero tensor shaped like ``target`` carrying ``values`` at ``indexes``."""
+  return torch.zeros_like(target).index_put_((indexes,), values)
+
+
 class VisibilityOptimizer(torch.optim.Optimizer):
   def __init__(self, kind: int, params, lr=0.001, betas=(0.9, 0.999), eps=1e-16, vis_beta=0.9,
                vis_smooth: float = 0.01, bias_correction=True, grad_clip: Optional[float] = None):

@@ -144,6 +144,7 @@ class _RankStep:
     self.run_word = torch.zeros((1,), dtype=torch.int32).pin_memory()
     self._run_np = self.run_word.numpy()
     self.mapper = _lib.MAPPER_DIRECT
+    self.bucket_overflowed = False   # host-side and sticky: poll() clears the device-written word, check() still reports it
     self.strict = frame.STRICT
     self.last_counters = None    # counters view of the last strip frame
     self.comm_bytes = {}
@@ -152,7 +153,7 @@ class _RankStep:
     """mapper + raster forward of this rank's strip: returns (keep_n, keep_k, image (strip rows only), alpha)"""
     lib = _lib.load()
     stream = _lib.current_stream(device)
-    if int(self._run_np[0]) > frame.LONG_RUN_LIMIT:
+    if int(self._run_np[0]) > frame.LONG_RUN_LIMIT or desc.depth16:     # 16-bit keys: pre-sort, as frame.py does
       self.mapper = _lib.MAPPER_PRESORT
     desc.mapper = self.mapper
     inputs.longest_run_host = self.run_word.data_ptr()
@@ -192,13 +193,20 @@ class _RankStep:
     return loss.detach(), g_image.contiguous()
 
   def check(self) -> dict:
-    """Host read (synchronises) of the device-side overflow flags of the LAST step."""
+    """Host read (synchronises the device) of the overflow indicators: the counters of the LAST step, and whether ANY
+    step since construction / ``reset_overflow()`` dropped splats in the exchange (``bucket_overflow`` is sticky on the
+    host: ``poll()`` clears the word the kernels write so that it can raise once per event, not the record)."""
+    torch.cuda.synchronize()       # the pinned words are written by kernels of the step: all of them have landed now
     k, live, over = (self.last_counters[:3].tolist() if self.last_counters is not None else (0, 0, 0))
-    if self.last_counters is None:
-      torch.cuda.synchronize()
+    self.bucket_overflowed = self.bucket_overflowed or bool(int(self._flags_np[0]))
     out = {"overlaps": k, "overlap_capacity": self.k_capacity, "overlap_overflow": bool(over),
-           "bucket_overflow": bool(int(self._flags_np[0]))}
+           "bucket_overflow": self.bucket_overflowed}
     return out
+
+  def reset_overflow(self):
+    """after a new probe(): forget earlier bucket overflows"""
+    self.bucket_overflowed = False
+    self._flags_np[0] = 0
 
   def poll(self):
     """Raise ``frame.FrameOverflow`` if a finished step exceeded a capacity (no synchronisation: pinned words).
@@ -206,6 +214,7 @@ class _RankStep:
     with ``MS_STRICT=1`` (``self.strict``) the step synchronises and raises for itself."""
     k = int(self._k_np[0])
     if self._flags_np[0]:
+      self.bucket_overflowed = True
       self._flags_np[0] = 0
       raise frame.FrameOverflow(f"rank {self.rank}: a destination bucket of the splat exchange overflowed (capacity "
                                 f"{getattr(self, 'bucket_capacity', 0)} rows): splats were dropped from a strip.  probe() again "
@@ -263,6 +272,7 @@ class StripStep(_RankStep):
 
   def probe(self, gaussians: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.15):
     """one synchronising dry run: fixes the overlap-list capacity of this rank's strip"""
+    self.reset_overflow()          # new capacities: earlier overflows no longer describe this step
     from .mapper.tile_mapper import map_to_tiles_strip
     from .perspective.projection import project_to_image
     with torch.no_grad():
@@ -381,6 +391,7 @@ class ShardedStep(_RankStep):
     """one synchronising dry run (a collective: every rank calls it): the largest per-destination bucket over all
     ranks fixes the bucket capacity, this rank's strip fixes its overlap-list capacity.  ``exchange``: the
     variable-size all-to-all of ``distributed.exchange_to_strips`` (default: RCCL)"""
+    self.reset_overflow()          # new capacities: earlier overflows no longer describe this step
     from .distributed import exchange_to_strips, _all_to_all
     from .mapper.tile_mapper import map_to_tiles_strip
     from .perspective.projection import project_to_image

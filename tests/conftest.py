@@ -53,3 +53,11 @@ def hostmath():
 
 def load_golden(name):
   return torch.load(GOLDEN / name, weights_only=False)
+
+
+def covariance_of(points):
+  """(V, 3) [a, b, c] of the 2D covariance [[a, b], [b, c]] = s1^2 u u^T + s2^2 w w^T rebuilt from a packed row's
+  (axis u, sigma): the well-conditioned content of the four columns — the axis of a nearly isotropic splat is not."""
+  p = torch.as_tensor(points).double()
+  ax, ay, s1, s2 = p[:, 2], p[:, 3], p[:, 4] ** 2, p[:, 5] ** 2
+  return torch.stack([s1 * ax * ax + s2 * ay * ay, (s1 - s2) * ax * ay, s1 * ay * ay + s2 * ax * ax], 1)

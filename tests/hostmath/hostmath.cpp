@@ -31,6 +31,30 @@ extern "C" void hm_project_fwd(const double* pos, const double* ls, const double
   }
 }
 
+// float32 instantiation of the projection forward (inputs / outputs travel as double, the arithmetic is float): the
+// conditioning of the eigen-pair in the PRODUCT precision (tests/test_hostmath.py::test_projection_forward_f32_covariance)
+extern "C" void hm_project_fwd_f32(const double* pos, const double* ls, const double* rot, const double* al,
+                                   const double* T, const double* P, int W, int H, double near_plane, double far_plane,
+                                   double blur, double margin, double thr, int64_t n, double* points7, double* depth,
+                                   int32_t* flag) {
+  Camera<float> cam;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) cam.t[i][j] = (float)T[i * 4 + j];
+  cam.fx = (float)P[0]; cam.fy = (float)P[1]; cam.cx = (float)P[2]; cam.cy = (float)P[3];
+  ProjParams<float> pp{(float)W, (float)H, (float)near_plane, (float)far_plane, (float)blur, (float)margin, (float)thr};
+  for (int64_t i = 0; i < n; ++i) {
+    float p[3], l[3], q[4];
+    for (int k = 0; k < 3; ++k) { p[k] = (float)pos[i * 3 + k]; l[k] = (float)ls[i * 3 + k]; }
+    for (int k = 0; k < 4; ++k) q[k] = (float)rot[i * 4 + k];
+    ProjState<float> st;
+    bool in_view = project_forward(p, l, q, (float)al[i], cam, pp, st);
+    double* o = points7 + i * 7;
+    o[0] = st.uv[0]; o[1] = st.uv[1]; o[2] = st.axis[0]; o[3] = st.axis[1];
+    o[4] = st.sigma[0]; o[5] = st.sigma[1]; o[6] = st.alpha;
+    depth[i] = st.pc[2];
+    flag[i] = in_view;
+  }
+}
+
 extern "C" void hm_project_bwd(const double* pos, const double* ls, const double* rot, const double* al,
                                const double* T, const double* P, int W, int H, double blur, double margin,
                                int64_t n, const double* g_points7, const double* g_depth, double* d_pos,

@@ -8,7 +8,7 @@ from oracle import projection as oproj, sh as osh
 from taichi_splatting_amd import evaluate_sh_at, RasterConfig, Gaussians3D
 from taichi_splatting_amd.perspective import projection as hip_proj, project_to_image
 from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
-from .conftest import load_golden
+from .conftest import covariance_of, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -44,6 +44,28 @@ def assert_f32_gradient_as_accurate_as_reference(got, w64, w32, what):
   assert err.median().item() < 1e-6, (what, 'median', err.median().item())
   q99, q99_ref = err.quantile(0.99).item(), ref.quantile(0.99).item()
   assert q99 <= q99_ref + 1e-6, (what, '99th percentile', q99, q99_ref)
+
+
+def assert_f32_forward_rows(h_out, o64_out):
+  """Float32 kernel outputs (points (V, 7), depth (V, 1), indexes) against the FLOAT64 oracle's on the rows both
+  keep: mean / sigma / alpha / depth to 1e-4 relative, and — the axis columns, which every comparison of rounds 1-4
+  dropped — the covariance rebuilt from (axis, sigma) to 1e-4 of its largest entry on every row (the kernels evaluate
+  the eigen-pair without the reference chain's cancellations, csrc/splat_math.h; measured on the host build: 4e-6,
+  torch_lib's float32 arithmetic: 2.6e-3) and the axis itself to 1e-3 (measured 3e-5)."""
+  idx_h, idx_o = h_out[2].cpu(), o64_out[2]
+  row_o = {int(k): j for j, k in enumerate(idx_o.tolist())}
+  keep = [j for j, k in enumerate(idx_h.tolist()) if int(k) in row_o]
+  if not keep:
+    return
+  got_p, got_d = h_out[0].cpu()[keep].double(), h_out[1].cpu()[keep].double()
+  sel = [row_o[int(idx_h[j])] for j in keep]
+  want_p, want_d = o64_out[0][sel].double(), o64_out[1][sel].double()
+  assert torch.allclose(got_p[:, [0, 1, 4, 5, 6]], want_p[:, [0, 1, 4, 5, 6]], rtol=1e-4, atol=1e-3)
+  assert torch.allclose(got_d, want_d, rtol=1e-4, atol=1e-5)
+  c_got, c_want = covariance_of(got_p), covariance_of(want_p)
+  rel = (c_got - c_want).abs().max(dim=1).values / c_want.abs().max(dim=1).values
+  assert rel.max().item() <= 1e-4, ('covariance from (axis, sigma)', rel.max().item())
+  assert (got_p[:, 2:4] - want_p[:, 2:4]).abs().max().item() <= 1e-3, 'axis'
 
 
 def _eval_with_grad(f, *args):
@@ -86,19 +108,18 @@ def test_projection_random_vs_oracle(seed):
     o_out, o_grad = _eval_with_grad(f_o, *inputs)
     h_out, h_grad = _eval_with_grad(f_h, *[t.to(DEV) for t in inputs])
     if dtype == torch.float64:
+      o64_out = o_out
       assert torch.equal(h_out[2].cpu(), o_out[2])
       assert torch.allclose(h_out[0].cpu(), o_out[0])
       assert torch.allclose(h_out[1].cpu(), o_out[1])
       for g_h, g_o in zip(h_grad, o_grad):
         assert torch.allclose(g_h.cpu(), g_o, rtol=1e-5, atol=1e-9), (g_h.cpu() - g_o).abs().max()
     else:
-      # f32 culling decisions may flip for gaussians numerically on the frustum boundary
+      # f32 culling decisions may flip for gaussians numerically on the frustum boundary: the rows BOTH evaluations keep
+      # are compared whatever the flips (rounds 1-4 compared nothing on a seed with a flip)
       a, b = set(h_out[2].cpu().tolist()), set(o_out[2].tolist())
       assert len(a ^ b) <= max(1, n // 2000), (len(a ^ b), n)
-      common = sorted(a & b)
-      if len(a ^ b) == 0:
-        assert torch.allclose(h_out[0].cpu()[:, [0, 1, 4, 5, 6]], o_out[0][:, [0, 1, 4, 5, 6]], rtol=1e-4, atol=1e-4)
-        assert torch.allclose(h_out[1].cpu(), o_out[1], rtol=1e-4, atol=1e-5)
+      assert_f32_forward_rows(h_out, o64_out)
 
 
 @pytest.mark.parametrize('seed', range(8))
@@ -107,8 +128,8 @@ def test_projection_f32_backward_vs_oracle(seed):
   ill-conditioned in float32 for some gaussians (eigen-decomposition of a near-isotropic blurred covariance,
   quaternion normalisation): torch_lib's own arithmetic evaluated in float32 misses the float64 gradients by up
   to ~10 % of the largest gradient on such rows, so the float32 kernels are held to
-    the criterion of assert_f32_gradient_as_accurate_as_reference: 1e-4 on >= 99 % of the gaussians and, everywhere,
-    the accuracy torch_lib's own arithmetic reaches in float32."""
+    the criterion of assert_f32_gradient_as_accurate_as_reference: 1e-4 on >= 99.9 % of the gaussians, none beyond
+    1e-3, never fewer rows within 1e-4 than torch_lib's own arithmetic reaches in float32."""
   torch.manual_seed(seed)
   camera = random_camera()
   n = 4000
@@ -140,9 +161,8 @@ def test_projection_f32_backward_vs_oracle(seed):
   o32, g32 = run(f_o, in32)
   oh, gh = run(f_h, in_h)
   assert torch.equal(oh[2].cpu(), o64[2])
-  # forward: mean, sigma, alpha, depth to 1e-4 relative; the axis of a near-isotropic splat is ill-conditioned
-  assert torch.allclose(oh[0].cpu()[:, [0, 1, 4, 5, 6]].double(), o64[0][:, [0, 1, 4, 5, 6]], rtol=1e-4, atol=1e-3)
-  assert torch.allclose(oh[1].cpu().double(), o64[1], rtol=1e-4, atol=1e-6)
+  # forward: mean, sigma, alpha, depth to 1e-4 relative, the covariance rebuilt from (axis, sigma) to 1e-4
+  assert_f32_forward_rows(oh, o64)
   for name, got, w64, w32 in zip(('position', 'log_scaling', 'rotation', 'alpha_logit', 'T_camera_world', 'projection'), gh, g64, g32):
     assert_f32_gradient_as_accurate_as_reference(got.cpu(), w64, w32, name)
 

@@ -1,0 +1,25 @@
+"""Round 5, CPU: the reference's module-level names of optim/visibility_aware.py, frame bookkeeping under failure."""
+import pytest
+import torch
+
+
+def test_visibility_aware_public_helpers_match_the_reference_signatures():
+  # reference optim/visibility_aware.py:11-52: get_running_vis, lerp, max_decaying, power_lerp, update_visibility,
+  # set_indexes are importable module-level names with these argument orders
+  from taichi_splatting_amd.optim.visibility_aware import (get_running_vis, lerp, max_decaying, power_lerp, set_indexes,
+                                                            update_visibility)
+  torch.manual_seed(0)
+  running, seen, idx = torch.rand(100), torch.rand(30), torch.randperm(100)[:30]
+  before = running.clone()
+  weight = update_visibility(running, seen, idx, None, beta=0.9)
+  want = (seen ** 4 + (before[idx] ** 4 - seen ** 4) * 0.9) ** 0.25        # power_lerp(beta, visibility, running, k=4)
+  assert torch.allclose(running[idx], want) and torch.allclose(weight, seen / want.clamp_min(1e-12))
+  untouched = torch.ones(100, dtype=torch.bool); untouched[idx] = False
+  assert torch.equal(running[untouched], before[untouched])
+  assert torch.allclose(power_lerp(0.9, seen, before[idx], k=4), want)
+  assert torch.allclose(lerp(0.25, seen, before[idx]), seen + (before[idx] - seen) * 0.25)
+  assert torch.allclose(max_decaying(0.25, seen, before[idx]), torch.maximum(seen, lerp(0.25, seen, before[idx])))
+  scattered = set_indexes(before, seen, idx)
+  assert torch.equal(scattered[idx], seen) and int((scattered != 0).sum()) == 30 and scattered.shape == before.shape
+  state = {}
+  assert get_running_vis(state, 5, torch.device('cpu')).shape == (5,) and 'running_vis' in state
