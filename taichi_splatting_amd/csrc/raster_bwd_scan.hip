@@ -49,6 +49,20 @@
 #ifndef MS_SCAN_ABLATE
 #define MS_SCAN_ABLATE 0
 #endif
+// -DMS_SCAN_PHASES=1: every wave adds up the shader cycles (s_memtime) it spends in each phase of the kernel
+// (g_scan_phase, read with ms_debug_scan_phases; tools/phase_split.py) — where a wave's wall time goes, parked or not
+#ifndef MS_SCAN_PHASES
+#define MS_SCAN_PHASES 0
+#endif
+// Round 5: the phases of a wave that are NOT the blend are latency bound (tools/rbench.py with the -DMS_SCAN_PHASES
+// build: 52 % of a wave's cycles on config D), and every one of them parks the wave while its SIMD could blend.
+//   staging        the gathered splat data is turned into LDS records in REGISTERS before the pass's commit and written
+//                  after the barrier: consuming a loaded register after the commit's global atomics costs
+//                  s_waitcnt vmcnt(0), i.e. the round trip of every atomic (loads and atomics share the counter);
+//                  one barrier instead of the three of __syncthreads_and at the top of a batch
+//   commit         point ids of the patch list resolved once per pass (into the dead sub-patch lists), so that a commit
+//                  step is one LDS round trip instead of three dependent ones
+//   cull           both cull levels issue all their LDS reads before the first test
 #ifndef MS_GRID_MOMENTS
 #define MS_GRID_MOMENTS 1           // 0: per-pixel moment sums in the splat's frame (rounds 2-3), kept for A/B builds
 #endif
@@ -72,6 +86,20 @@ namespace ms {
 #if MS_SCAN_STATS
 __device__ unsigned long long g_scan_stats[12];
 #endif
+#if MS_SCAN_PHASES
+// 0 barrier at the top of a batch   1 staging (record transform + next gathers)   2 barrier after staging
+// 3 cull (both levels)   4 chunk prologue (list -> patch list -> record reads landed, set-up)   5 blend (16 steps)
+// 6 chunk epilogue (read-add-write of the sums)   7 commit (global atomics)   8 kernel start .. first batch
+// 9 whole wave   10 chunks   11 waves
+// one row of 12 counters per wave (no atomics: 65 536 waves adding to the same 12 words serialise for milliseconds and
+// the queue of their atomics delays every other wave's commit)
+__device__ unsigned long long* g_scan_phase_rows = nullptr;
+#define MS_PH(i) do { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[i] += (uint32_t)(ph_now - ph_last); ph_last = ph_now; } while (0)
+#define MS_PH_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)      // lgkmcnt(0): LDS reads of the phase have landed
+#else
+#define MS_PH(i) do {} while (0)
+#define MS_PH_LGKM0() do {} while (0)
+#endif
 
 // Deterministic mode: the per-(patch, splat) sums are committed as 64-bit fixed-point integers with INTEGER atomics.
 // Integer addition is associative, so the accumulated row does not depend on the order in which the patches of
@@ -94,8 +122,11 @@ __global__ void fixed_point_exponents_kernel(const float* __restrict__ amax, int
 // TS x TS quarter.  Tile 32 runs as <16, HEUR, 2>: with one 1024-thread workgroup per tile a staged splat touches
 // few of the 16 patches and the per-wave lists stay short (4.0 ms on config D against 1.5 ms at tile 16); a
 // quarter stages the whole list (2.8x the splats that touch it) and then works exactly like a 16 x 16 tile.
+// Four waves per SIMD (<= 128 VGPRs) is what the 40 KB of LDS per tile-16 workgroup allow, and the kernel is written
+// to that budget; without the bound the register allocator of ROCm 7.2 lets the tile-16 instantiation drift to 137
+// registers, i.e. three waves (tile 8 is LDS-bound at three waves per SIMD whatever it uses).
 template <int TS, bool HEUR, int SPLIT = 1>
-__global__ void __launch_bounds__(TS * TS)
+__global__ void __launch_bounds__(TS * TS, TS == 8 ? 1 : 4)
 raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
                        const float* __restrict__ image, const float* __restrict__ grad_image,
@@ -133,13 +164,22 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // atomics (ds_add_f32 costs ~160 LDS cycles per instruction on gfx950, tools/ubench_scan.hip)
   __shared__ float s_acc[WAVES][CAP][NACC];
   __shared__ uint16_t s_plist[WAVES][CAP];       // patch-list position -> staged index
-  __shared__ uint8_t s_list[WAVES][4][CAP];      // per sub-patch: patch-list positions of its hits, depth ordered
+  // per sub-patch: patch-list positions of its hits, depth ordered.  (MS_OPT_COMMIT: once a pass has blended, the 4 * CAP
+  // bytes of a wave hold the CAP point ids of its patch list for the commit.)
+  __shared__ __attribute__((aligned(16))) uint8_t s_list[WAVES][4][CAP];
+  static_assert((4 * CAP) % 4 == 0, "a wave's lists double as CAP ints");
   // per-pixel data, read by ALL lanes of the wave at the pixel's step (same address: LDS broadcast; v_readlane
   // from state registers costs ~12-16 cycles per value on gfx950, tools/ubench_scan.hip):
   // [dL/dC.rgb, T] and <R, G>; entry p = 16 * sub-patch + 4 * y + x
   __shared__ float4 s_pix[WAVES][64];
   __shared__ float s_rg[WAVES][64];
+  __shared__ int s_done[WAVES];                  // per wave: every pixel of its patch is saturated (tile-wide early out)
 
+#if MS_SCAN_PHASES
+  const uint64_t ph_start = __builtin_readcyclecounter();
+  uint64_t ph_last = ph_start;
+  uint32_t ph_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   unsigned quarter_u;
   // the quarter workgroups of a tile run on one XCD (they stage the same list); tiles themselves in plain order
   const int local_tile = xcd_tile<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, blockIdx.x, SPLIT * SPLIT, &quarter_u);
@@ -176,6 +216,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   for (int i = lane; i < CAP * NACC; i += 64) (&s_acc[wave][0][0])[i] = 0.0f;
 
   const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
+  if (end <= start) return;        // (uniform over the workgroup; the staging below reads the tile's list unguarded)
 
   // equal batches: as many as it takes to stay near BATCH_TARGET (rounded to nearest), never above BATCH
   const int total = end - start;
@@ -184,18 +225,78 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   int bsz = (total + num_batches - 1) / num_batches;
   if (bsz > BATCH) { num_batches = (total + BATCH - 1) / BATCH; bsz = (total + num_batches - 1) / num_batches; }
 
-  // two-deep gather pipeline per staging slot: `raw` = splat data of the batch about to be staged, `next_id` =
-  // point index of the batch after it
-  Raw raw, raw_b;
-  int next_id = 0, next_id_b = 0;
+  // Staging pipeline (tile 16 / 32: thread t stages slot t of every batch), three batches deep:
+  //   rec / rec_id   finished LDS record of the NEXT batch, made at the stage point of the batch before it
+  //   raw            gathered data in flight for the batch after that
+  //   next_id        point index one batch further on
+  // The stage point of a batch sits after its last blend and BEFORE the commit that follows: a register filled by a
+  // gather may only be read when no global atomic has been issued behind the gather — loads and atomics share vmcnt,
+  // the count of atomics is not known at compile time, and the wait the compiler then places is vmcnt(0): the round
+  // trip of every atomic of the commit (round 4 read the gathered data after the barrier that follows the commit: 7 %
+  // of a wave's cycles, tools/rbench.py with the -DMS_SCAN_PHASES build).  The records wait in registers across the
+  // commit and the barrier and are dead during the blend.
+  // Every load of the pipeline is UNCONDITIONAL (list positions beyond the tile's run are clamped to its last entry, and
+  // what they fetch is never written to LDS) and stage_next() has ONE call site: the compiler counts outstanding loads
+  // per straight-line path, so a divergent branch around a load, or two sites whose registers must be unified at the
+  // loop header, each cost a vmcnt(0) — the full latency of gathers issued a few instructions earlier.
+  Raw raw = {};
+  int next_id = 0;
+  ScanRecord rec = {};
+  int rec_id = 0;
+  auto list_pos = [&](int j, int sl) { const int i = start + j * bsz + sl; return i < end ? i : end - 1; };
+  // The SLOTS_B slots beyond the workgroup's thread count (tile 16: 268 - 256 = 12) are gathered ONE COMPONENT PER LANE
+  // — slot PRIMARY + (t >> 4), component t & 15: 7 geometry floats, 3 colour floats, the point id (re-read from the
+  // list as the lane's "component") — so that they cost every thread two registers instead of a second raw + record
+  // set (24 + 13): b_val in flight, b_nid the next id; the slot's leader lane assembles the record in the slot's own LDS
+  // space once the barrier has released it.  Lanes without a component load something harmless.
+  constexpr int B_THREADS = 16 * SLOTS_B;
+  static_assert(B_THREADS <= THREADS, "one lane per component of the extra slots");
+  const int b_slot = PRIMARY + ((t >> 4) < (SLOTS_B > 0 ? SLOTS_B : 1) ? (t >> 4) : 0), b_comp = t & 15;
+  const bool b_lane = SLOTS_B > 0 && t < B_THREADS && b_comp <= 10;
+  float b_val = 0.0f, b_hold = 0.0f;
+  int b_nid = 0;
+  // per-lane address as integer arithmetic (a select between the three POINTERS becomes a table in scratch memory)
+  const bool b_geom = b_comp < 7, b_col = b_comp >= 7 && b_comp < 10;
+  auto b_load = [&](int id, int j) {
+    const uint64_t pa = reinterpret_cast<uint64_t>(points), fa = reinterpret_cast<uint64_t>(feats),
+                   oa = reinterpret_cast<uint64_t>(o2p);
+    const uint64_t a_geom = pa + 4ull * (uint64_t)((int64_t)id * 7 + (b_geom ? b_comp : 0));
+    const uint64_t a_col = fa + 4ull * (uint64_t)((int64_t)id * 3 + (b_col ? b_comp - 7 : 0));
+    const uint64_t a_id = oa + 4ull * (uint64_t)list_pos(j, b_slot);
+    uint64_t addr = b_geom ? a_geom : (b_col ? a_col : a_id);
+    asm volatile("" : "+v"(addr));          // (one load, whatever the component; nothing here is loop invariant)
+    return *reinterpret_cast<const __attribute__((address_space(1))) float*>(addr);
+  };
+  // The pipeline fills through the SAME stage_next() call as it runs (the batch loop below starts two stage points
+  // early): a second site that loads `raw` would make the loop header unify two register assignments of the in-flight
+  // data with copies — and a copy of a register that is being loaded is a vmcnt(0).
   if (PIPELINED) {
-    if (t < bsz && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
-    if (t < bsz && start + bsz + t < end) next_id = o2p[start + bsz + t];
-    if (t < SLOTS_B) {
-      if (PRIMARY + t < bsz && start + PRIMARY + t < end) raw_b = load_raw(points, feats, o2p[start + PRIMARY + t]);
-      if (PRIMARY + t < bsz && start + bsz + PRIMARY + t < end) next_id_b = o2p[start + bsz + PRIMARY + t];
-    }
+    next_id = o2p[list_pos(0, t)];
+    if (SLOTS_B > 0) b_nid = o2p[list_pos(0, b_slot)];
   }
+  // the stage point of batch `batch`: records of batch + 1 from the data that has landed, gathers of batch + 2, ids of
+  // batch + 3
+  auto stage_next = [&](int batch) {
+    if (!PIPELINED) return;
+    rec = make_scan_record(raw, rp.alpha_threshold); rec_id = raw.id;
+    // the record is finished before the gathers are issued: they then load straight into the registers of `raw`.  Left
+    // to itself the scheduler hoists the loads above the record arithmetic, lands them in fresh registers and copies
+    // them home at the loop latch — behind the commit, i.e. with a wait for every atomic of the commit again.
+    asm volatile("" : "+v"(rec.r0.x), "+v"(rec.r0.y), "+v"(rec.r0.z), "+v"(rec.r0.w), "+v"(rec.r1.x), "+v"(rec.r1.y),
+                      "+v"(rec.r1.z), "+v"(rec.r1.w), "+v"(rec.r2.x), "+v"(rec.r2.y), "+v"(rec.r2.z), "+v"(rec.r2.w), "+v"(rec_id));
+    __builtin_amdgcn_sched_barrier(0);
+    // (the id travels on in a register of its own, made by an instruction the compiler cannot fold: the load of the
+    // next id then lands in next_id's register instead of a fresh one that is copied over behind the commit)
+    int gather_id;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(gather_id) : "v"(next_id));
+    raw = load_raw(points, feats, gather_id);
+    next_id = o2p[list_pos(batch + 3, t)];
+    if (SLOTS_B > 0) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(b_hold) : "v"(b_val));       // the gathered component is consumed HERE
+      b_val = b_load(b_nid, batch + 2);
+      b_nid = o2p[list_pos(batch + 3, b_slot)];
+    }
+  };
 
 #if MS_SCAN_STATS
   __shared__ int s_bsum, s_bmax;
@@ -207,12 +308,66 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     s_bsum = 0; s_bmax = 0;                                                                                     \
   }
 #endif
-  for (int begin = start; begin < end; begin += bsz) {
+  // ---- commit of a pass: ONE 64-byte, line-aligned row of global float atomics per (patch, splat) ----------------
+  // ROWS_PER rows of NACC sums per instruction (7 x 9 = 63 lanes; 5 x 11 with heuristics): the LDS reads sweep
+  // the wave's accumulator block linearly and the loop runs pcount / 7 times (16 lanes per row, 9 of them with
+  // data, ran pcount / 4 times: 1.45 -> 1.37 ms on config D; the atomics themselves are 0.10 ms of instruction
+  // rate + 0.04 ms of misses: 1.33 ms when every row lands in a 16 MB window, 1.21 ms without the commit).
+  // Round 5: the pass has blended, so its sub-patch lists are dead and take the point ids of the patch list (two
+  // dependent reads, once per pass, 64 entries at a time): a commit step is then ONE LDS round trip — the sums and the id
+  // of its rows — requested a step ahead, where round 4 walked sum -> staged index -> point id for every step
+  // (10.7 % of a wave's cycles on config D).
+  auto commit_pass = [&](int pcount) {
+    constexpr int ROWS_PER = 64 / NACC;
+    const int sub_row = lane / NACC, k = lane - sub_row * NACC;
+    const bool lane_used = sub_row < ROWS_PER;
+    int* s_pid = reinterpret_cast<int*>(&s_list[wave][0][0]);
+    for (int pp = lane; pp < pcount; pp += 64) s_pid[pp] = s_id[s_plist[wave][pp]];
+    wave_lds_fence();
+    float v = 0.0f;
+    int point = 0;
+    if (lane_used && sub_row < pcount) { v = s_acc[wave][sub_row][k]; point = s_pid[sub_row]; }
+    for (int e0 = 0; e0 < pcount; e0 += ROWS_PER) {
+      const int e = e0 + sub_row, en = e + ROWS_PER;
+      float vn = 0.0f;
+      int pointn = 0;
+      if (lane_used && en < pcount) { vn = s_acc[wave][en][k]; pointn = s_pid[en]; }
+      if (v != 0.0f) {
+        const size_t word = (size_t)(uint32_t)point * MOMENT_ROW + k;
+        if (rp.deterministic)
+          __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
+                                 (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          atomic_add_noret(moments + word, v);
+        s_acc[wave][e][k] = 0.0f;
+      }
+      v = vn; point = pointn;
+    }
+    wave_lds_fence();
+  };
+
+  for (int batch = PIPELINED ? -2 : 0;; ++batch) {
+    bool wave_alive = false;
+    int pcount = 0;
+    if (batch >= 0) {
+    const int begin = start + batch * bsz;
+    if (begin >= end) break;
     const int count = (end - begin) < bsz ? (end - begin) : bsz;
     // all waves are done with the previous batch; tile-wide early out once every pixel is saturated
     // (backward.py:116)
     wave_lds_fence();
-    const bool tile_done = __syncthreads_and(__float_as_uint(s_pix[wave][lane].w) <= oms_bits);
+#if MS_SCAN_PHASES
+    if (batch == 0) MS_PH(8);
+#endif
+    // one barrier (__syncthreads_and is a DPP reduction, an LDS word and THREE s_barrier on gfx950)
+    {
+      const bool wave_done = __ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits) == 0;
+      if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+    }
+    __syncthreads();
+    const bool tile_done = __ballot(s_done[lane % WAVES] != 0) == ~0ull;
+    MS_PH(0);
 #if MS_SCAN_STATS
     MS_FLUSH_BALANCE()
 #endif
@@ -220,19 +375,27 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
     if (PIPELINED) {
       if (t < count) {
-        write_scan_record(raw, rp.alpha_threshold, &s_rec[t * 3]);
-        s_id[t] = raw.id;
+        s_rec[t * 3 + 0] = rec.r0; s_rec[t * 3 + 1] = rec.r1; s_rec[t * 3 + 2] = rec.r2;
+        s_id[t] = rec_id;
       }
-      if (t < bsz && begin + bsz + t < end) raw = load_raw(points, feats, next_id);
-      if (t < bsz && begin + 2 * bsz + t < end) next_id = o2p[begin + 2 * bsz + t];
-      if (t < SLOTS_B) {
-        const int sb = PRIMARY + t;
-        if (sb < count) {
-          write_scan_record(raw_b, rp.alpha_threshold, &s_rec[sb * 3]);
-          s_id[sb] = raw_b.id;
+      if (SLOTS_B > 0 && PRIMARY < count) {
+        // the extra slots: every component lane drops its value into the slot's own (released) record space, the
+        // slot's leader lane reads the ten floats back, makes the record and overwrites them
+        int bs = b_slot;
+        asm volatile("" : "+v"(bs));       // (the slot's LDS addresses are made here, not kept in registers for the whole kernel)
+        if (b_lane && bs < count) {
+          if (b_comp < 10) reinterpret_cast<float*>(&s_rec[bs * 3])[b_comp] = b_hold;
+          else s_id[bs] = __float_as_int(b_hold);
         }
-        if (sb < bsz && begin + bsz + sb < end) raw_b = load_raw(points, feats, next_id_b);
-        if (sb < bsz && begin + 2 * bsz + sb < end) next_id_b = o2p[begin + 2 * bsz + sb];
+        wave_lds_fence();
+        if (t < B_THREADS && b_comp == 0 && bs < count) {
+          const float4 x0 = s_rec[bs * 3 + 0], x1 = s_rec[bs * 3 + 1], x2 = s_rec[bs * 3 + 2];
+          Raw rb;
+          rb.g[0] = x0.x; rb.g[1] = x0.y; rb.g[2] = x0.z; rb.g[3] = x0.w; rb.g[4] = x1.x; rb.g[5] = x1.y; rb.g[6] = x1.z;
+          rb.f[0] = x1.w; rb.f[1] = x2.x; rb.f[2] = x2.y;
+          rb.id = 0;
+          write_scan_record(rb, rp.alpha_threshold, &s_rec[bs * 3]);
+        }
       }
     } else {
       for (int s = t; s < count; s += THREADS) {
@@ -241,12 +404,15 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         s_id[s] = r.id;
       }
     }
+    MS_PH(1);
     __syncthreads();
+    MS_PH(2);
 
-    // wave-wide early out (backward.py:142)
-    if (__ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits) == 0) continue;
+    // wave-wide early out (backward.py:142): a wave whose 64 pixels are saturated skips the passes — but not the batch's
+    // stage point below (one site for every path)
+    wave_alive = __ballot(__float_as_uint(s_pix[wave][lane].w) > oms_bits) != 0;
 #if MS_SCAN_ABLATE == 2
-    continue;
+    wave_alive = false;
 #endif
 
 #if MS_SCAN_STATS
@@ -256,14 +422,25 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #endif
     // From here to the next barrier the wave works alone: it walks the staged batch in passes of at most CAP
     // patch hits (one pass per batch unless most staged splats touch this 8x8 patch).
+    // The LAST pass of a batch is committed below the loop, behind the batch's stage point.
     int r = 0;
-    while (r < count) {
+    while (wave_alive) {
       // ---- cull, level 1: the staged splats that can touch this wave's 8x8 patch -> patch list ------------------
-      int pcount = 0;
+      pcount = 0;
       const float pcx = (float)patch_x + 4.0f, pcy = (float)patch_y + 4.0f;
+      // the records of the NEXT 64 staged splats are requested before the current 64 are tested: one exposed LDS round
+      // trip per pass instead of one per group (a lane beyond the batch reads record 0 and ignores it)
+      auto group_records = [&](int first, float4& a, float4& b) {
+        const int j = first + lane < count ? first + lane : 0;
+        a = s_rec[j * 3 + 0]; b = s_rec[j * 3 + 1];
+      };
+      float4 g0, g1;
+      group_records(r, g0, g1);
       while (r < count) {
+        float4 n0 = g0, n1 = g1;
+        if (r + 64 < count) group_records(r + 64, n0, n1);
         const int j = r + lane;
-        const bool hit = j < count && scan_rect_hit(s_rec[j * 3 + 0], s_rec[j * 3 + 1], s_rec[j * 3 + 2], pcx, pcy, 3.5f);
+        const bool hit = j < count && scan_rect_hit(g0, g1, pcx, pcy, 3.5f);
         const unsigned long long m = __ballot(hit);
         const int nhit = __builtin_popcountll(m);
         if (pcount + nhit > CAP) break;          // next pass (nhit <= 64 <= CAP: an empty list always takes the group)
@@ -271,30 +448,42 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         if (hit) s_plist[wave][ppos] = (uint16_t)j;
         pcount += nhit;
         r += 64;
+        g0 = n0; g1 = n1;
       }
       wave_lds_fence();
       // ---- cull, level 2: only the patch hits (about 40 % of a batch) are tested against the four 4x4 sub-patches;
       // both lists are appended in order, so they stay depth sorted
       int cnt[4] = {0, 0, 0, 0};
-      for (int g = 0; g < pcount; g += 64) {
-        const int ppos = g + lane;
-        const bool in = ppos < pcount;
-        const int j = in ? (int)s_plist[wave][ppos] : 0;
-        const float4 q0 = s_rec[j * 3 + 0], q1 = s_rec[j * 3 + 1], q2 = s_rec[j * 3 + 2];
+      {
+        // CAP <= 128: at most two groups of patch hits; their staged indices, then their records, are requested
+        // together (two exposed round trips per pass instead of two per group)
+        static_assert(CAP <= 128, "level-2 cull: two groups");
+        const bool two = pcount > 64;
+        const bool in_a = lane < pcount, in_b = 64 + lane < pcount;
+        const int ja = in_a ? (int)s_plist[wave][lane] : 0;
+        const int jb = (two && in_b) ? (int)s_plist[wave][64 + lane] : 0;
+        const float4 a0 = s_rec[ja * 3 + 0], a1 = s_rec[ja * 3 + 1];
+        float4 b0 = a0, b1 = a1;
+        if (two) { b0 = s_rec[jb * 3 + 0]; b1 = s_rec[jb * 3 + 1]; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
-          const bool hit = in && scan_rect_hit(q0, q1, q2, rcx, rcy, 1.5f);
-          const unsigned long long m = __ballot(hit);
-          const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (hit) s_list[wave][q][pos] = (uint8_t)ppos;
-          cnt[q] += __builtin_popcountll(m);
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+          const bool in = u == 0 ? in_a : in_b;
+          const float4 q0 = u == 0 ? a0 : b0, q1 = u == 0 ? a1 : b1;
+          const int ppos = u * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float rcx = (float)(patch_x + (q & 1) * 4) + 2.0f, rcy = (float)(patch_y + (q >> 1) * 4) + 2.0f;
+            const bool hit = in && scan_rect_hit(q0, q1, rcx, rcy, 1.5f);
+            const unsigned long long m = __ballot(hit);
+            const int pos = cnt[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (hit) s_list[wave][q][pos] = (uint8_t)ppos;
+            cnt[q] += __builtin_popcountll(m);
+          }
         }
       }
       wave_lds_fence();
-#if MS_SCAN_ABLATE == 1
-      continue;
-#endif
+      MS_PH(3);
 #if MS_SCAN_STATS
       if (lane == 0) {
         atomicAdd(&g_scan_stats[0], 1ull);                                                      // passes
@@ -304,6 +493,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #endif
 
       // ---- blend: lane = splat, 16 pixel steps per chunk ------------------------------------------------------
+#if MS_SCAN_ABLATE != 1
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {
         const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
@@ -322,8 +512,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           const int idx = (int)s_plist[wave][pos];
           const float4 q0 = s_rec[idx * 3 + 0], q1 = s_rec[idx * 3 + 1], q2 = s_rec[idx * 3 + 2];
           const float A = q0.z, B = q0.w, C = q1.x, D = q1.y;
-          const float nl2a = valid ? q1.z : __builtin_inff();       // idle lanes: alpha g = exp2(-inf) = 0
-          const float f0 = q1.w, f1 = q2.x, f2 = q2.y;
+          const float nl2a = valid ? q2.x : __builtin_inff();       // idle lanes: alpha g = exp2(-inf) = 0
+          const float f0 = q2.y, f1 = q2.z, f2 = q2.w;
           const float dx0 = fx - q0.x, dy0 = fy - q0.y;             // first pixel centre of the sub-patch - mean
           const float X00 = A * dx0 + B * dy0, Y00 = C * dx0 + D * dy0;
           // (X', Y') at the first pixel of each of the four pixel rows; a step adds x * (A, C)
@@ -345,6 +535,11 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           const float gx0 = __builtin_fmaf(X00, A, Y00 * C), gy0 = __builtin_fmaf(X00, B, Y00 * D);
 #if MS_SCAN_STATS
           int steps_run = 0, lanes_contrib = 0;
+#endif
+#if MS_SCAN_PHASES
+          MS_PH_LGKM0();
+          MS_PH(4);
+          ++ph_acc[10];
 #endif
 
           // Two instantiations of the 16 steps, chosen per chunk (wave-uniform): the grid form expands X, Y around the
@@ -509,6 +704,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           }
 #endif
 
+          MS_PH(5);
           // this wave's row of the splat: the lanes of a chunk hold distinct splats, chunks run one after the other
           if (valid) {
             float* row = &s_acc[wave][pos][0];
@@ -516,42 +712,36 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #pragma unroll
             for (int k = 0; k < NACC; ++k) row[k] += v[k];
           }
+          MS_PH(6);
         }
       }
 
-      // ---- commit the pass: ONE 64-byte, line-aligned row of global float atomics per (patch, splat) ------------
+#endif      // MS_SCAN_ABLATE != 1
       wave_lds_fence();
-      // ROWS_PER rows of NACC sums per instruction (7 x 9 = 63 lanes; 5 x 11 with heuristics): the LDS reads sweep
-      // the wave's accumulator block linearly and the loop runs pcount / 7 times (16 lanes per row, 9 of them with
-      // data, ran pcount / 4 times: 1.45 -> 1.37 ms on config D; the atomics themselves are 0.10 ms of instruction
-      // rate + 0.04 ms of misses: 1.33 ms when every row lands in a 16 MB window, 1.21 ms without the commit)
-      {
-        constexpr int ROWS_PER = 64 / NACC;
-        const int sub_row = lane / NACC, k = lane - sub_row * NACC;
-        const bool lane_used = sub_row < ROWS_PER;
-        for (int e0 = 0; e0 < pcount; e0 += ROWS_PER) {
-          const int e = e0 + sub_row;
-          if (lane_used && e < pcount) {
-            const float v = s_acc[wave][e][k];
-            if (v != 0.0f) {
-              const size_t word = (size_t)(uint32_t)s_id[s_plist[wave][e]] * MOMENT_ROW + k;
-              if (rp.deterministic)
-                __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
-                                       (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else
-                atomic_add_noret(moments + word, v);
-              s_acc[wave][e][k] = 0.0f;
-            }
-          }
-        }
-      }
-      wave_lds_fence();
+      MS_PH(4);        // (the sub-patch loop's own bookkeeping between the last chunk and the commit)
+      if (r >= count) break;       // last pass of the batch: committed below, behind the stage point
+      commit_pass(pcount);
+      MS_PH(7);
     }
 #if MS_SCAN_STATS
     if (lane == 0) { atomicAdd(&s_bsum, batch_chunks); atomicMax(&s_bmax, batch_chunks); }
 #endif
+    }       // batch >= 0
+    // stage point: the gathers issued a batch ago have landed and no atomic is in flight behind them
+    stage_next(batch);
+    MS_PH(1);
+    if (wave_alive) commit_pass(pcount);
+    MS_PH(7);
   }
+#if MS_SCAN_PHASES
+  if (lane == 0 && g_scan_phase_rows) {
+    const uint64_t ph_end = __builtin_readcyclecounter();
+    unsigned long long* row = g_scan_phase_rows + ((size_t)blockIdx.x * WAVES + wave) * 12;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) row[i] = ph_acc[i];
+    row[9] = ph_end - ph_start; row[10] = ph_acc[10]; row[11] = 1;
+  }
+#endif
 #if MS_SCAN_STATS
   __syncthreads();
   MS_FLUSH_BALANCE()
@@ -722,6 +912,15 @@ extern "C" int ms_fixed_point_exponents(const float* amax_dev, int32_t* out_exp2
   MS_CHECK_LAUNCH();
   return 0;
 }
+
+#if MS_SCAN_PHASES
+// rows: device buffer of (waves of the launch) x 12 uint64 the next launches fill (NULL: stop recording)
+extern "C" int ms_debug_scan_phases(unsigned long long* rows, int unused) {
+  (void)unused;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_scan_phase_rows), &rows, sizeof(rows));
+  return 0;
+}
+#endif
 
 #if MS_SCAN_STATS
 extern "C" int ms_debug_scan_stats(unsigned long long* out10, int reset) {

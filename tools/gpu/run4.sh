@@ -1,0 +1,12 @@
+mkdir -p gpurun_out/r5d
+for sc in D dense E; do
+  MS_SPLAT_LIB=tools/abl/libbase.so python tools/rbench.py --scene $sc --save /tmp/ref$sc.pt --tag base > gpurun_out/r5d/base_$sc.txt 2>&1
+  python tools/rbench.py --scene $sc --ref /tmp/ref$sc.pt --tag new > gpurun_out/r5d/new_$sc.txt 2>&1
+done
+MS_SPLAT_LIB=tools/abl/libphases.so python tools/rbench.py --scene D --ref /tmp/refD.pt > gpurun_out/r5d/phases_D.txt 2>&1
+for t in 8 32; do
+  MS_SPLAT_LIB=tools/abl/libbase.so python tools/rbench.py --scene D --tile $t --save /tmp/refD$t.pt --tag base$t > gpurun_out/r5d/base_D$t.txt 2>&1
+  python tools/rbench.py --scene D --tile $t --ref /tmp/refD$t.pt --tag new$t > gpurun_out/r5d/new_D$t.txt 2>&1
+done
+grep -h RBENCH gpurun_out/r5d/*.txt
+timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_raster.py -x -q -m gpu > gpurun_out/r5d/pytest.txt 2>&1; tail -3 gpurun_out/r5d/pytest.txt
