@@ -63,6 +63,9 @@
 //   commit         point ids of the patch list resolved once per pass (into the dead sub-patch lists), so that a commit
 //                  step is one LDS round trip instead of three dependent ones
 //   cull           both cull levels issue all their LDS reads before the first test
+#ifndef MS_COMMIT_ABLATE
+#define MS_COMMIT_ABLATE 0
+#endif
 #ifndef MS_GRID_MOMENTS
 #define MS_GRID_MOMENTS 1           // 0: per-pixel moment sums in the splat's frame (rounds 2-3), kept for A/B builds
 #endif
@@ -338,8 +341,16 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
                                  (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
+        else {
+#if MS_COMMIT_ABLATE == 0
           atomic_add_noret(moments + word, v);
+#elif MS_COMMIT_ABLATE == 1          // timing experiments (wrong gradients): one lane per row
+          if (k == 0) atomic_add_noret(moments + word, v);
+#elif MS_COMMIT_ABLATE == 2          // plain stores to the same addresses
+          moments[word] = v;
+#elif MS_COMMIT_ABLATE == 3          // no global traffic at all
+#endif
+        }
         s_acc[wave][e][k] = 0.0f;
       }
       v = vn; point = pointn;
