@@ -257,12 +257,13 @@ raster_fwd_kernel(const T* __restrict__ points, const T* __restrict__ feats,
             W += weight;
 #pragma unroll
             for (int c = 0; c < F; ++c) C[c] += s.f[c] * weight;
-          } else if (!saturated) {
-            // quantile render (forward.py:107-112): take the feature of the splat at which the
-            // accumulated weight first reaches 1 - saturate_threshold
+          } else {
+            // quantile render (forward.py:102-112): the weight keeps accumulating for every gated splat (it is what
+            // `visibility` sums in this mode too, forward.py:114-126); the pixel takes the feature of the splat at which
+            // the accumulated weight FIRST reaches 1 - saturate_threshold
             weight = alpha * (T(1) - W);
             W += weight;
-            if (W >= T(1) - rp.saturate_threshold) {
+            if (!saturated && W >= T(1) - rp.saturate_threshold) {
 #pragma unroll
               for (int c = 0; c < F; ++c) C[c] = s.f[c];
               saturated = true;
@@ -484,7 +485,10 @@ static void launch_fwd(const void* points, const void* feats, const int32_t* ran
   raster_fwd_kernel<T, F, TS, AA, BLEND, VIS><<<grid, block, 0, s>>>(                                 \
       (const T*)points, (const T*)feats, ranges, o2p, rp, (T*)image, (T*)alpha, (T*)vis)
   const bool aa = cfg->antialias, blend = cfg->use_alpha_blending, visf = cfg->compute_visibility && vis;
-  if (!blend) { if (aa) MS_FWD(true, false, false); else MS_FWD(false, false, false); }
+  if (!blend) {
+    if (aa) { if (visf) MS_FWD(true, false, true); else MS_FWD(true, false, false); }
+    else { if (visf) MS_FWD(false, false, true); else MS_FWD(false, false, false); }
+  }
   else if (aa) { if (visf) MS_FWD(true, true, true); else MS_FWD(true, true, false); }
   else { if (visf) MS_FWD(false, true, true); else MS_FWD(false, true, false); }
 #undef MS_FWD

@@ -548,9 +548,6 @@ class _FrameFunction(torch.autograd.Function):
     else:
       assert feat.ndim == 2, f"Features must be (N, C) if use_sh=False, got {feat.shape}"
       f, degree = feat.shape[1], -1
-    if config.compute_visibility and not config.use_alpha_blending:
-      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
-                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
 
     rows = (0, tiles_high) if opts.tile_rows is None else (max(0, int(opts.tile_rows[0])), min(tiles_high, int(opts.tile_rows[1])))
     key = _shape_key(device, n, (w, h), config, opts.tile_rows, opts.use_depth16)
@@ -761,9 +758,6 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     assert features.ndim == 2 and features.shape[0] == gaussians2d.shape[0], \
       f"features must be (N, F), got {features.shape} for {gaussians2d.shape[0]} gaussians"
     assert features.dtype == gaussians2d.dtype, f"dtype mismatch {features.dtype} != {gaussians2d.dtype}"
-    if config.compute_visibility and not config.use_alpha_blending:
-      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
-                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
     p = gaussians2d.detach().contiguous()
     feats = features.detach().contiguous()
     dtype, device = p.dtype, p.device

@@ -102,12 +102,10 @@ class _RasterFunction(torch.autograd.Function):
     stream = _lib.current_stream(device)
     cfg_c = _lib.raster_config_c(config)
 
-    if config.compute_visibility and not config.use_alpha_blending:
-      # forward.py:114-126 keeps summing blend weights into `visibility` in quantile mode until all 32 lanes of a
-      # CUDA warp are saturated (forward.py:92-94): the result depends on the reference's thread -> pixel map and
-      # is not reproduced here.  render_gaussians disables visibility for its median pass (renderer.py:80).
-      raise ValueError("compute_visibility requires use_alpha_blending: the reference's visibility in quantile "
-                       "(use_alpha_blending=False) mode depends on its warp layout and is not reproduced")
+    # compute_visibility with use_alpha_blending=False (quantile render): forward.py:114-126 keeps summing the blend
+    # weights into `visibility`; here over EVERY gated splat of every pixel (the generic kernel has no early exit),
+    # which is what oracle/raster.py restates.  The reference stops a warp once its 32 pixels are saturated
+    # (forward.py:92-94), so its values are <= these and depend on its thread -> pixel map.
     if config.compute_point_heuristic and f > WIDE_KERNEL_FEATURES[-1]:
       raise NotImplementedError(f"compute_point_heuristic with {f} > {WIDE_KERNEL_FEATURES[-1]} feature channels: "
                                 "prune_cost / split_score need dL/dalpha over ALL channels at once")

@@ -8,8 +8,9 @@ Each configuration is checked twice:
     alpha > alpha_threshold are removed first (oracle.raster.gate_margin), so no float32 rounding can flip a
     gate.  Every pixel and every 2D-boundary gradient (d gaussians2d, d colour) must then agree to the 1e-4 of
     BASELINE.json's north_star with the float64 oracle rasterizer evaluated on the SAME float32 splats the kernels
-    rasterized (the rasterizer is judged on its inputs), and every pixel to 2e-4 with the all-float64 oracle
-    pipeline (the float32 projection perturbs the splat parameters by ~1e-6, a near-isotropic splat's axis by more).
+    rasterized (the rasterizer is judged on its inputs), and every pixel to 1e-4 with the all-float64 oracle
+    pipeline as well (round 5: the float32 projection no longer loses the axis of a nearly vertical splat), with the
+    counted, bounded exception of pixels whose float64 pipeline has a pair within 1e-4 of the blend gate.
     The gradients of the 3D parameters go through the projection backward.  The reference's formula chain is
     ill-conditioned in float32 for nearly isotropic blurred covariances (torch_lib's own arithmetic run in float32
     is off by 1e-3 ... 1e+3 times the largest gradient on such rows); since round 4 the kernels evaluate the
@@ -115,8 +116,11 @@ def oracle_leaf_grads_from_covariance(g, cam, cfg, p_h, gp_h, gf_h):
   return idx, [x.grad.double() for x in leaves]
 
 
-PROJECTION_SHIFT = 3e-3     # the float32 projection moves alpha * g by ~1e-6 relative in general and by up to ~1e-3
-                            # for nearly isotropic splats, whose axis is ill-conditioned
+PROJECTION_SHIFT = 1e-4     # margin (relative to the blend gate) inside which the float32 projection may flip a pair of the
+                            # float64 pipeline: it moves alpha * g by ~1e-6 relative (measured with the host build of
+                            # csrc/splat_math.h on these four scenes: every deviation explained at a margin of 3e-5, largest
+                            # error elsewhere 1.4e-5); rounds 1-4 needed 3e-3 for the ill-conditioned axis
+MAX_FLAGGED_END_TO_END = 2e-3   # share of the pixels that may sit that close to a gate at all (measured 0.6e-4 .. 2.5e-4)
 
 
 def gate_stable(g, cam, cfg, rel_margin=1e-4):
@@ -151,16 +155,20 @@ def test_downscaled_config_matches_oracle_f32(name, n, size, tile):
   gd = g.to(DEV).requires_grad_(True)
   r = render_gaussians(gd, cam.to(device=DEV), cfg, use_sh=True)
   assert torch.equal(r.points.idx.cpu(), want['idx'])                       # same visible set
-  # whole pipeline against the float64 oracle pipeline, every pixel: the float32 projection moves the splat
-  # parameters by ~1e-6 relative (the axis of a nearly isotropic splat by up to ~1e-3 rad), which shows up as up to
-  # ~1e-4 in a pixel — or as a flipped gate where the float64 splat has a pair within PROJECTION_SHIFT of the
-  # threshold.  Every pixel beyond 2e-4 must be such a pixel (count of unexplained ones: zero); the rasterizer
-  # itself is held to 1e-4 on its own inputs below
+  # whole pipeline against the float64 oracle pipeline, every pixel, at the north_star's 1e-4: since round 5 the float32
+  # projection evaluates the eigen-pair without the reference chain's cancellations (csrc/splat_math.h), so it moves
+  # alpha * g by ~1e-6 relative, axis included (rounds 1-4: up to ~1e-3 for a nearly vertical / isotropic splat, which is
+  # why this comparison excused every pixel within 3e-3 of a gate and asserted only 2e-4 elsewhere).  The criterion is
+  # the one of the unfiltered-scene tests (gate_excess.check_pixels): a pixel beyond 1e-4 must have a (pixel, splat)
+  # pair of the FLOAT64 pipeline within PROJECTION_SHIFT of the blend gate, may move by at most 2 alpha_threshold max|f|
+  # per such pair, and there may be at most MAX_PIXELS_BEYOND of them; the flagged share itself is capped.
   err = (r.image.detach().cpu().double() - want['image']).abs().max(-1).values
   err = torch.maximum(err, (r.image_weight.detach().cpu().double() - want['alpha']).abs())
-  pixel_flag, _ = orast.near_gate(want['points'].detach(), want['ranges'], want['o2p'], size, cfg, PROJECTION_SHIFT)
-  unexplained = (err > 2e-4) & ~pixel_flag
-  assert int(unexplained.sum()) == 0, (name, int(unexplained.sum()), float(err[unexplained].max()))
+  pixel_flag, _, pixel_count = orast.near_gate(want['points'].detach(), want['ranges'], want['o2p'], size, cfg,
+                                               PROJECTION_SHIFT, return_counts=True)
+  assert float(pixel_flag.float().mean()) <= MAX_FLAGGED_END_TO_END, (name, float(pixel_flag.float().mean()))
+  check_pixels(err, pixel_flag, pixel_count, float(want['feats'].abs().max()), cfg.alpha_threshold,
+               f"end to end, {name}", max_fraction=MAX_PIXELS_BEYOND)
   r.points.gaussians2d.retain_grad()
   r.points.features.retain_grad()
   (r.image * G.to(DEV).float()).sum().backward()

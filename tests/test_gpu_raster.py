@@ -187,12 +187,31 @@ def test_point_heuristics_with_wide_features(channels, dtype):
     rasterize_with_tiles(pg.detach(), wide, o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
 
 
-def test_quantile_mode_rejects_visibility():
-  size = (32, 32)
-  p, f, d, o2p, ranges = scene(100, size, seed=1, channels=1)
-  cfg = RasterConfig(use_alpha_blending=False, compute_visibility=True)
-  with pytest.raises(ValueError, match='compute_visibility'):
-    rasterize_with_tiles(p.to(DEV), f.to(DEV), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_quantile_mode_visibility_vs_oracle(dtype):
+  """use_alpha_blending=False + compute_visibility (forward.py:102-126): the weight keeps accumulating past the
+  quantile and `visibility` sums it for every gated splat.  Against the oracle's restatement (untruncated sums; the
+  reference itself stops a warp once its 32 pixels are saturated — its values are <= these), through
+  rasterize_with_tiles AND the frame executor (rasterize)."""
+  from taichi_splatting_amd import rasterize
+  size = (96, 64)
+  cfg = RasterConfig(use_alpha_blending=False, compute_visibility=True, saturate_threshold=0.3)
+  p, f, d, o2p, ranges = scene(1500, size, seed=3, scale=2.0, alpha=(0.3, 0.9), channels=1)
+  p64, f64 = p.double(), f.double()
+  img_o, a_o, vis_o = orast.forward(p64, f64, ranges, o2p, size, cfg)
+  assert float(vis_o.max()) > 1.0                       # sums over many pixels, past the quantile
+  tol = 1e-9 if dtype == torch.float64 else 2e-5
+  out = rasterize_with_tiles(p.to(DEV, dtype), f.to(DEV, dtype), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg)
+  assert torch.equal(out.image_weight.cpu().double(), a_o)
+  assert (out.visibility.cpu().double() - vis_o).abs().max().item() <= tol * float(vis_o.max())
+  out2 = rasterize(p.to(DEV, dtype), d.to(DEV, dtype), f.to(DEV, dtype), size, cfg)
+  assert (out2.visibility.cpu().double() - vis_o).abs().max().item() <= tol * float(vis_o.max())
+  if dtype == torch.float64:
+    assert ((out.image.cpu() - img_o).abs().max(-1).values > 1e-12).float().mean() < 1e-3      # (quantile ties: see below)
+  # the blending weights are the same numbers: with blending on, the same splats get the same visibility
+  cfg_b = RasterConfig(use_alpha_blending=True, compute_visibility=True)
+  out_b = rasterize_with_tiles(p.to(DEV, dtype), f.to(DEV, dtype), o2p.to(DEV), ranges.to(DEV).view(-1, 2), size, cfg_b)
+  assert (out_b.visibility.cpu().double() - vis_o).abs().max().item() <= max(tol, 2e-5) * float(vis_o.max())
 
 
 def test_quantile_render_no_blending():

@@ -1,0 +1,165 @@
+"""-m gpu, round 5: scene shapes the bench scene does not have — heavy-tailed splat sizes
+(the wave-cooperative walk of wide tile spans in the count / emit kernels), tiles whose lists go on long after every
+pixel is opaque (the forward's spent-tile exit) — and the staging pipeline of the raster backward on tile lists of
+every length class (1, 2, 3, 4+ batches; slots beyond the workgroup's thread count)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mapper as omap, raster as orast
+from taichi_splatting_amd import RasterConfig, frame, map_to_tiles, rasterize_with_tiles, render_gaussians
+from taichi_splatting_amd.misc.renderer2d import project_gaussians2d
+from taichi_splatting_amd.testing import random_2d_gaussians, random_3d_gaussians, random_camera
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def heavy_tail_2d(n, size, seed, share=0.05, factor=20.0):
+  torch.manual_seed(seed)
+  g = random_2d_gaussians(n, size, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  big = torch.rand(n) < share
+  g.log_scaling[:] = g.log_scaling + math.log(factor) * big[:, None].float()
+  return g, big
+
+
+@pytest.mark.parametrize('tile', [8, 16, 32])
+def test_heavy_tailed_sizes_count_emit_and_lists(tile):
+  """5 % of the splats at 20 x scale: a wave of the count / emit kernels holds spans of 1-4 tiles next to spans of
+  hundreds, which the whole wave walks (csrc/mapper.hip).  Lists against the numpy oracle (reference order: tile, depth
+  bits, point index), both sequences identical, count == emit (the ranges partition [0, K))."""
+  size = (512, 384)
+  g, big = heavy_tail_2d(12000, size, seed=tile)
+  assert int(big.sum()) > 300
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
+  p, depth = project_gaussians2d(g), g.depths.reshape(-1, 1).clone()
+  want_o2p, want_ranges, _ = omap.map_to_tiles(p.numpy(), depth.reshape(-1).numpy(), size, tile, cfg.alpha_threshold)
+  lists = {}
+  for method in ('direct', 'presort'):
+    o2p, ranges = map_to_tiles(p.to(DEV), depth.to(DEV), size, cfg, method=method)
+    lists[method] = (o2p.cpu(), ranges.cpu())
+    r2 = ranges.view(-1, 2).cpu()
+    live = r2[r2[:, 1] > r2[:, 0]]
+    assert int(live[0, 0]) == 0 and int(live[-1, 1]) == o2p.shape[0] and bool((live[1:, 0] == live[:-1, 1]).all())
+  assert torch.equal(lists['direct'][0], lists['presort'][0]) and torch.equal(lists['direct'][1], lists['presort'][1])
+  o2p, ranges = lists['direct']
+  assert o2p.shape[0] == want_o2p.shape[0], (o2p.shape[0], want_o2p.shape[0])
+  assert np.array_equal(ranges.view(-1, 2).numpy(), np.asarray(want_ranges).reshape(-1, 2))
+  assert np.array_equal(o2p.numpy(), np.asarray(want_o2p))
+  # the wide spans really were there: a big splat covers dozens of tiles
+  spans = torch.bincount(o2p.long(), minlength=p.shape[0])
+  assert int(spans[big].max()) > 64 and float(spans[~big].float().mean()) < 16
+
+
+def test_heavy_tailed_scene_settles_on_the_presort_sequence_with_the_same_image():
+  """render_gaussians on a heavy-tailed 3D scene: the overlap total per gaussian is far above the crossover, so the
+  frame executor maps with the pre-sort from the second frame on (the first frame of a shape runs the default), and the
+  frames agree bit for bit (same lists, same kernels)."""
+  torch.manual_seed(5)
+  size = (512, 512)
+  cam = random_camera(image_size=size)
+  n = 40000
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  big = torch.rand(n) < 0.05
+  g = g.replace(log_scaling=g.log_scaling + math.log(20.0) * big[:, None].float(), feature=torch.rand(n, 3))
+  cfg = RasterConfig()
+  frame.release_caches()
+  try:
+    gd, camd = g.to(DEV), cam.to(device=DEV)
+    images, modes = [], []
+    for _ in range(3):
+      with torch.no_grad():
+        images.append(render_gaussians(gd, camd, cfg, use_sh=False).image.clone())
+      key = frame._shape_key(torch.device(DEV), n, size, cfg, None, False)
+      modes.append(frame._mapper_mode.get(key))
+    from taichi_splatting_amd import _lib
+    assert modes[-1] == _lib.MAPPER_PRESORT, modes
+    assert torch.equal(images[0], images[1]) and torch.equal(images[1], images[2])
+  finally:
+    frame.release_caches()
+
+
+def pile_2d(n, size, window, sigma, seed, alpha_range=(0.5, 0.95)):
+  torch.manual_seed(seed)
+  g = random_2d_gaussians(n, size, scale_factor=1.0, alpha_range=alpha_range)
+  g.position[:] = torch.tensor([[window[0], window[1]]], dtype=torch.float32) + window[2] * torch.rand(n, 2)
+  g.log_scaling[:] = torch.log(torch.full((n, 2), sigma))
+  return g
+
+
+@pytest.mark.parametrize('tile', [8, 16, 32])
+def test_forward_stops_on_spent_tiles_without_changing_the_image(tile):
+  """20 000 fairly opaque splats on a 40 x 40 px window: every pixel there is opaque after a few dozen splats and the
+  product forward leaves the tile's list (csrc/raster_fast.hip, FWD_SPENT_T); the float64 generic kernel walks all of
+  it, like the reference (forward.py:69-70 never sets its flag when blending).  Image, image weight and the per-splat
+  visibility must agree to float32 rounding."""
+  size = (160, 128)
+  g = pile_2d(20000, size, (50.0, 40.0, 40.0), 1.5, seed=tile)
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2))
+  cfg_v = RasterConfig(tile_size=tile, pixel_stride=cfg.pixel_stride, compute_visibility=True)
+  p, depth, f = project_gaussians2d(g).to(DEV), g.depths.reshape(-1, 1).to(DEV), g.feature.to(DEV)
+  o2p, ranges = map_to_tiles(p, depth, size, cfg)
+  assert int((ranges[..., 1] - ranges[..., 0]).max()) > 3000
+  with torch.no_grad():
+    got = rasterize_with_tiles(p, f, o2p, ranges.view(-1, 2), size, cfg)
+    got_v = rasterize_with_tiles(p, f, o2p, ranges.view(-1, 2), size, cfg_v)
+    want = rasterize_with_tiles(p.double(), f.double(), o2p, ranges.view(-1, 2), size, cfg_v)
+  assert (got.image.double() - want.image).abs().max().item() < 2e-6
+  assert (got.image_weight.double() - want.image_weight).abs().max().item() < 2e-6
+  assert torch.equal(got.image, got_v.image)
+  assert float(want.image_weight.max()) > 0.9999                       # the window really is opaque
+  vis, vis64 = got_v.visibility.double(), want.visibility
+  assert (vis - vis64).abs().max().item() < 1e-5 * float(vis64.max())
+  # and against the oracle (the reference's loop restated), every pixel
+  img, alpha, _ = orast.forward(p.cpu().double(), f.cpu().double(), ranges.cpu(), o2p.cpu(), size, cfg)
+  assert (got.image.cpu().double() - img).abs().max().item() < 1e-5
+  assert (got.image_weight.cpu().double() - alpha).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize('per_tile', [40, 250, 268, 269, 530, 800, 1100, 2300])
+def test_backward_staging_pipeline_on_every_list_length(per_tile):
+  """The raster backward stages a tile's list in equal batches of <= 268 splats through a three-deep register pipeline
+  whose last 12 slots travel one component per lane (csrc/raster_bwd_scan.hip, round 5).  Tile lists of 40 ... 2300
+  entries — one batch with and without the extra slots, exactly 268 and 269, two, three, four and nine batches — against
+  the pixel-per-lane kernels of raster_fast.hip (MS_RASTER_BWD=patch) on low-opacity splats (nothing saturates: every
+  batch blends)."""
+  import os
+  size = (64, 48)                                    # 4 x 3 tiles of 16
+  n = per_tile * 12
+  torch.manual_seed(per_tile)
+  g = random_2d_gaussians(n, size, scale_factor=0.6, alpha_range=(0.01, 0.03))
+  # one splat per (tile, slot): centres inside their tile, small enough to stay there
+  tiles = torch.arange(n) % 12
+  g.position[:] = torch.stack([(tiles % 4) * 16 + 3.0 + 10.0 * torch.rand(n), (tiles // 4) * 16 + 3.0 + 10.0 * torch.rand(n)], 1)
+  g.log_scaling[:] = torch.log(0.5 + 0.4 * torch.rand(n, 2))
+  cfg = RasterConfig(tile_size=16)
+  p0, depth, f0 = project_gaussians2d(g).to(DEV), g.depths.reshape(-1, 1).to(DEV), g.feature.to(DEV)
+  o2p, ranges = map_to_tiles(p0, depth, size, cfg)
+  runs = (ranges[..., 1] - ranges[..., 0]).flatten()
+  assert int(runs.min()) >= per_tile and int(runs.max()) <= per_tile + 40
+  torch.manual_seed(1)
+  G = torch.rand(size[1], size[0], 3, device=DEV) + 0.5
+  grads = {}
+  for mode in ('scan', 'patch'):
+    os.environ['MS_RASTER_BWD'] = mode
+    try:
+      p, f = p0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+      out = rasterize_with_tiles(p, f, o2p, ranges.view(-1, 2), size, cfg)
+      (out.image * G).sum().backward()
+      grads[mode] = (p.grad.clone(), f.grad.clone())
+    finally:
+      os.environ.pop('MS_RASTER_BWD', None)
+  # every gradient row to 2e-5 of the largest gradient, except the odd splat with a pixel on the blend gate (the two
+  # kernels round alpha * g differently; one flipped pair moves that splat's row): at most two such rows (and a handful behind them at that pixel), none of the
+  # size a dropped or misplaced slot would cause (those lose a whole splat: relative error of order 1 on its row)
+  for a, b, what in zip(grads['scan'], grads['patch'], ('gaussians2d', 'features')):
+    scale = float(b.abs().max())
+    rel = (a - b).abs().max(dim=1).values / scale
+    assert int((rel > 2e-5).sum()) <= max(8, 0.003 * rel.numel()) and int((rel > 1e-3).sum()) <= max(2, 0.0005 * rel.numel()), \
+      (what, per_tile, int((rel > 2e-5).sum()), int((rel > 1e-3).sum()), float(rel.max()))
+    assert float(rel.max()) < 0.2, (what, per_tile, float(rel.max()))
+    own = (a - b).abs().max(dim=1).values / b.abs().max(dim=1).values.clamp_min(1e-3 * scale)
+    assert int((own > 0.5).sum()) == 0, (what, per_tile, "a splat lost most of its gradient")
+    assert float(a.abs().max()) > 0
