@@ -148,6 +148,19 @@ def stage_breakdown(g, cam, cfg, use_sh):
     ranges2 = ranges.view(-1, 2)
     out['raster_fwd'] = cuda_time_ms(lambda: rasterize_with_tiles(g2d, feats, o2p, ranges2, cam.image_size, cfg))
     image = rasterize_with_tiles(g2d, feats, o2p, ranges2, cam.image_size, cfg).image
+    # the forward kernel alone through the C-ABI, like the backward below (`raster_fwd` is the modular operator: it
+    # also allocates its outputs and hands back the RasterOut tuple)
+    fwd_image, fwd_alpha = torch.empty_like(image), torch.empty(image.shape[:2], dtype=image.dtype, device=image.device)
+    wf, hf = cam.image_size
+    g2d_c, feats_c = g2d.contiguous(), feats.contiguous()
+    cfg_f = _lib.raster_config_c(cfg)
+
+    def fwd_kernel():
+      _lib.check(lib.ms_raster_fwd(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), wf, hf, 3, cfg_f,
+                                   fwd_image.data_ptr(), fwd_alpha.data_ptr(), None, 0, (hf + cfg.tile_size - 1) // cfg.tile_size,
+                                   _lib.dtype_code(torch.float32), _lib.current_stream(g2d.device)), "bench raster_fwd")
+    if feats.shape[1] == 3 and g2d.dtype == torch.float32:
+      out['raster_fwd_kernel'] = cuda_time_ms(fwd_kernel, iters=10, warmup=2)
 
     # the dominant kernel, timed alone through the C-ABI
     grad_image = torch.ones_like(image)
@@ -599,6 +612,16 @@ def main():
                           "note": "alpha-composite passes are VALU bound at these K*tile^2 (SURVEY 8d); see compute"}
     if compute:
       result["roofline"]["compute"] = compute
+      work = load_work()
+      if work and 'counts' in work:
+        vr = valu_roofline(work, compute, stages[dom])
+        result["roofline"]["compute"]["valu_roofline"] = vr
+        if vr.get("gather_only_ms"):
+          # the HBM-roofline fraction this kernel could reach if culling, blending and committing cost NOTHING: its
+          # algorithmic bytes over the time the chip needs to gather the tile lists' rows (random 128-byte lines)
+          result["roofline"]["frac_ceiling"] = round(alg[dom] / (vr["gather_only_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+          result["roofline"]["frac_ceiling_is"] = ("algorithmic bytes / time of the kernel's gathers alone (-DMS_SCAN_ABLATE=2 build, "
+                                                   "same box as the counters): the >= 0.5 target is above it")
     # frame-level fraction: the reference's formula (6-pass 64-bit key sort) and the bytes THIS design moves
     # (ceil(log2 T / 8) stable passes over K (tile << 32 | depth key, point) pairs, 12 bytes read + 12 written each,
     # then the per-tile depth sort: 12 bytes read, 4 written per overlap; csrc/tile_sort.hip)
@@ -653,6 +676,55 @@ def load_counters(args, w, h):
   return t.get('traffic_bytes'), t.get('compute'), {"file": str(COUNTER_FILE.relative_to(ROOT)), "kernel_source_sha16": have,
                                                     "collected": t.get('collected'),
                                                     "traffic_is": t.get('traffic_correction', "FETCH_SIZE + WRITE_SIZE, raw")}
+
+
+# Lane-instructions ONE contributing (pixel, splat) pair needs in this algorithm, however the pairs are laid out over
+# lanes (backward.py:144-200 with the moment form of csrc/raster_bwd_scan.hip): X, Y (2 FMA) . exponent (2 FMA) . v_exp_f32
+# . gate (compare + select) . clamp . 1 - alpha . T (1 - alpha) . w = alpha T . <f, G> (3) . <R, G> -= w <f, G> . v_rcp_f32 .
+# d(alpha) (2) . q = alpha d(alpha) . six moment sums (6) . three colour sums (3)
+MIN_LANE_INSTR_PER_PAIR = 31
+
+
+def load_work():
+  try:
+    return json.load(open(COUNTER_FILE)).get('work')
+  except Exception:
+    return None
+
+
+def valu_roofline(work, compute, kernel_ms):
+  """The compute roofline of the dominant kernel, formally: what the launch HAS to compute —
+  its contributing (pixel, splat) pairs x the lane-instructions a pair needs — against what it issues, and the time
+  floors the measured phases set.  Everything but `kernel_ms` comes from profiles/raster_bwd_counters.json (collected
+  on these kernel sources: same fingerprint rule as `traffic`)."""
+  c = work['counts']
+  pairs = c['pairs']
+  algorithmic = pairs * MIN_LANE_INSTR_PER_PAIR / 64.0
+  issued = compute['valu_instr_per_launch']
+  peak_instr_s = compute['peak'] * 1e9                       # wave64 VALU instructions / s at 2 cycles each
+  cycles = compute['static_mix']['issue_cycles_per_instr'] if compute.get('static_mix') else 2.0
+  out = {
+    "contributing_pairs": pairs, "min_lane_instr_per_pair": MIN_LANE_INSTR_PER_PAIR,
+    "algorithmic_instr": int(algorithmic), "issued_instr": issued, "frac": round(algorithmic / issued, 4),
+    "is": "wave64 VALU instructions at 64 of 64 lanes useful / instructions issued",
+    "lanes_contributing_per_pixel_step": c['pairs_per_step'], "chunk_fill_of_64": c['fill'],
+    "algorithmic_ms_at_issue_peak": round(algorithmic / peak_instr_s * 1e3, 4),
+    "issued_ms_at_measured_mix": round(issued * cycles / 2.0 / peak_instr_s * 1e3, 4),
+    "kernel_ms": round(kernel_ms, 4),
+  }
+  for key in ('blend_alone_floor_ms',):
+    if key in work:
+      out[key] = work[key]
+  alone = work.get('kernel_ms_same_box', {})
+  if 'staging_only_ms' in alone:
+    # the gathers of the tile lists alone (no cull, blend, commit): what the memory system needs for them at its
+    # 128-byte-line rate — the kernel's HBM roofline fraction cannot exceed algorithmic bytes / this time
+    out["gather_only_ms"] = alone['staging_only_ms']
+  if 'no_commit_traffic_ms' in alone and 'product_ms' in alone:
+    out["commit_costs_ms"] = round(alone['product_ms'] - alone['no_commit_traffic_ms'], 4)
+  if 'wave_cycle_share' in work:
+    out["wave_cycle_share"] = work['wave_cycle_share']
+  return out
 
 
 def graph_step_ms_in_child(args):

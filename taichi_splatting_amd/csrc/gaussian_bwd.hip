@@ -66,6 +66,10 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
   __shared__ T s_Y[DEG >= 0 ? 4 : 1][DEG >= 0 ? 64 * YS : 1];
   __shared__ T s_g[DEG >= 0 ? 4 : 1][DEG >= 0 ? 64 * GB_MAX_F : 1];
   __shared__ T s_cam[4 * 16];
+  // FIXED: the wave's 64 fixed-point rows (64 x 128 bytes, contiguous) come in as coalesced 16-byte loads, are turned
+  // into floats on the way and handed to their lanes through LDS (round 5; a lane walking its own row with twelve
+  // 8-byte loads and stores made this pass 0.43 -> 1.16 ms on config D)
+  __shared__ float4 s_mom[(MOM && FIXED) ? 4 : 1][(MOM && FIXED) ? 64 * 3 : 1];
 
   const int wave = threadIdx.x >> 6, lane = lane_id();
   T cam_grad[16];
@@ -92,6 +96,26 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
     T dp[3] = {T(0), T(0), T(0)}, dls[3] = {T(0), T(0), T(0)}, dq[4] = {T(0), T(0), T(0), T(0)}, dal = T(0);
     T heur0 = T(0), heur1 = T(0);
 
+    if constexpr (MOM && FIXED) {
+      struct alignas(16) Pair { long long lo, hi; };
+      Pair* blk = reinterpret_cast<Pair*>(reinterpret_cast<long long*>(a.moments) + base * MS_MOMENT_ROW);
+      const double s_main = ldexp(1.0, -a.fixed_exp[0]), s_h0 = ldexp(1.0, -a.fixed_exp[1]);
+      float* flat = reinterpret_cast<float*>(&s_mom[wave][0]);
+      wave_lds_fence();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = j * 64 + lane, row = idx >> 3, pair = idx & 7;      // values 2 pair, 2 pair + 1 of row `row`
+        if (row < count) {
+          const Pair v = blk[idx];
+          blk[idx] = Pair{0, 0};                                             // whole lines go back as zeros
+          if (pair < 6) {
+            flat[row * 12 + 2 * pair] = (float)((double)v.lo * s_main);
+            flat[row * 12 + 2 * pair + 1] = (float)((double)v.hi * (pair == 4 ? s_h0 : s_main));     // value 9: its own unit
+          }
+        }
+      }
+      wave_lds_fence();
+    }
     if (vis) {
       const T p[3] = {a.position[i * 3 + 0], a.position[i * 3 + 1], a.position[i * 3 + 2]};
       const T ls[3] = {a.log_scaling[i * 3 + 0], a.log_scaling[i * 3 + 1], a.log_scaling[i * 3 + 2]};
@@ -104,15 +128,7 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         // the row is re-zeroed for the next frame
         float4 r0, r1, r2;
         if constexpr (FIXED) {
-          long long* row = reinterpret_cast<long long*>(a.moments) + i * MS_MOMENT_ROW;
-          const int e_main = a.fixed_exp[0], e_h0 = a.fixed_exp[1];
-          float v[12];
-#pragma unroll
-          for (int k = 0; k < 12; ++k) {
-            v[k] = (float)ldexp((double)row[k], k == 9 ? -e_h0 : -e_main);
-            row[k] = 0;
-          }
-          r0 = make_float4(v[0], v[1], v[2], v[3]); r1 = make_float4(v[4], v[5], v[6], v[7]); r2 = make_float4(v[8], v[9], v[10], v[11]);
+          r0 = s_mom[wave][lane * 3 + 0]; r1 = s_mom[wave][lane * 3 + 1]; r2 = s_mom[wave][lane * 3 + 2];
         } else {
           float4* row = reinterpret_cast<float4*>(reinterpret_cast<float*>(a.moments) + i * MS_MOMENT_ROW);
           r0 = row[0]; r1 = row[1]; r2 = row[2];

@@ -66,6 +66,19 @@
 #ifndef MS_COMMIT_ABLATE
 #define MS_COMMIT_ABLATE 0
 #endif
+// wave priority: 1 = the blend phase runs at raised priority (s_setprio 2), 2 = everything BUT the blend does, 0 = off.
+// Same box, config D: off 1.340-1.345 ms, blend raised 1.334, the rest raised 1.376 — the issue-bound phase should not
+// lose slots to waves that are about to park on a load anyway.
+#ifndef MS_PRIO_MODE
+#define MS_PRIO_MODE 1
+#endif
+#if MS_PRIO_MODE == 1
+#define MS_PRIO_BLEND(on) __builtin_amdgcn_s_setprio((on) ? 2 : 0)
+#elif MS_PRIO_MODE == 2
+#define MS_PRIO_BLEND(on) __builtin_amdgcn_s_setprio((on) ? 0 : 2)
+#else
+#define MS_PRIO_BLEND(on) do {} while (0)
+#endif
 #ifndef MS_GRID_MOMENTS
 #define MS_GRID_MOMENTS 1           // 0: per-pixel moment sums in the splat's frame (rounds 2-3), kept for A/B builds
 #endif
@@ -182,6 +195,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   const uint64_t ph_start = __builtin_readcyclecounter();
   uint64_t ph_last = ph_start;
   uint32_t ph_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+#if MS_PRIO_MODE == 2
+  __builtin_amdgcn_s_setprio(2);
 #endif
   unsigned quarter_u;
   // the quarter workgroups of a tile run on one XCD (they stage the same list); tiles themselves in plain order
@@ -505,6 +521,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
       // ---- blend: lane = splat, 16 pixel steps per chunk ------------------------------------------------------
 #if MS_SCAN_ABLATE != 1
+      MS_PRIO_BLEND(true);
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {
         const int n = q == 0 ? cnt[0] : q == 1 ? cnt[1] : q == 2 ? cnt[2] : cnt[3];
@@ -727,6 +744,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         }
       }
 
+      MS_PRIO_BLEND(false);
 #endif      // MS_SCAN_ABLATE != 1
       wave_lds_fence();
       MS_PH(4);        // (the sub-patch loop's own bookkeeping between the last chunk and the commit)

@@ -2,7 +2,7 @@
 """Condense the rocprofv3 PMC passes of tools/pmc_collect.sh (summary.json) into the committed counter file that
 bench.py reads for `roofline.traffic` and `roofline.compute`:
 
-    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K [bwd.s fwd.s] > profiles/raster_bwd_counters.json
+    python tools/pmc_to_profile.py gpurun_out/pmc_xxx/summary.json N SIZE TILE K [bwd.s fwd.s] [--work work.json] > profiles/raster_bwd_counters.json
 
 The file carries `kernel_source_sha16` (bench.py::kernel_source_sha16 of the tree it is generated in — run it on the
 tree the counters were collected on) and the collection date: bench.py attaches the figures only to a binary built
@@ -32,6 +32,11 @@ import sys
 # of the 64-byte sectors) touched by random 28- / 32-byte row gathers; WRITE_SIZE x 1024 equals the bytes written.  The
 # x2 therefore applies to every access pattern of these kernels and `traffic_bytes` is 2 x FETCH + WRITE.
 FETCH_CORRECTION = 2.0
+work_file = None
+if '--work' in sys.argv:          # tools/work_counters.py output: what the launch computes, and the phase floors
+  i = sys.argv.index('--work')
+  work_file = sys.argv[i + 1]
+  del sys.argv[i:i + 2]
 summary, n, size, tile, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 asm = sys.argv[6:8] if len(sys.argv) >= 8 else None
 d = json.load(open(summary))
@@ -103,4 +108,6 @@ result = {
                                                      "exec_lane_util", "clock_ghz", "valu_instr_per_launch")},
   "raster_bwd": bwd, "raster_fwd": fwd,
 }
+if work_file:
+  result["work"] = json.load(open(work_file))
 print(json.dumps(result, indent=1))
