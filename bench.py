@@ -76,6 +76,11 @@ def parse_args():
                  help='N > 1: number of camera poses the timed loop cycles through (a trainer visits a different view '
                       'every step).  Strip bounds and buffer capacities are per view, probed once per view outside the '
                       'timed region — the per-epoch cost a trainer amortises over its views; 1 = one static camera')
+  p.add_argument('--dry-run', action='store_true',
+                 help='N > 1 without N GPUs: --gpus N ranks of a gloo group share cuda:0 and run the SAME rank steps, probes and '
+                      'bookkeeping collectives as the RCCL run (device tensors staged through the host); every rank logs the '
+                      'collectives it issues (operation, shapes, dtypes, split lists) and rank 0 checks that the sequences match '
+                      'across ranks and that every all-to-all split pairs up.  Times mean nothing in this mode')
   p.add_argument('--launcher', action='store_true',
                  help='re-execute under torch.distributed.run even for --gpus 1 (exercises the RCCL path on one GPU)')
   return p.parse_args()
@@ -290,7 +295,7 @@ def respawn_under_torchrun(args):
   rank per GPU of this node, rendezvous on 127.0.0.1.  Fails loudly when the node has fewer GPUs."""
   import subprocess
   have = torch.cuda.device_count()
-  if have < args.gpus:
+  if have < args.gpus and not args.dry_run:
     print(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr)
     sys.exit(2)
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
@@ -455,7 +460,7 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
     barrier()
   per_rank = [mine]
   if distributed:
-    t = torch.tensor([elapsed, mine], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, mine], dtype=torch.float64, device='cpu' if args.dry_run else device)
     all_t = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(all_t, t)
     elapsed = max(float(x[0]) for x in all_t)
@@ -488,9 +493,15 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.dry_run:
+      local_rank = 0                          # every rank on the one GPU; collectives through gloo + host memory
     torch.cuda.set_device(local_rank)
     import datetime
-    dist.init_process_group('nccl', timeout=datetime.timedelta(seconds=300))     # a hung collective fails the run, it does not stall it
+    dist.init_process_group('gloo' if args.dry_run else 'nccl',
+                            timeout=datetime.timedelta(seconds=300))     # a hung collective fails the run, it does not stall it
+    if args.dry_run:
+      from taichi_splatting_amd import distributed as dist_mod
+      dist_mod.collective_log = []
   device = torch.device('cuda', local_rank)
   torch.cuda.set_device(device)
   job = {"world_size": world, "backend": None, "devices": [torch.cuda.get_device_name(device)]}
@@ -635,6 +646,9 @@ def main():
 
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result["cpu_baseline"] = cpu_baseline(args)
+  if distributed and args.dry_run:
+    result["dry_run"] = check_collective_logs(rank, world)
+    result["data"] = "synthetic (DRY RUN: gloo ranks sharing one GPU; times are not measurements)"
 
   if rank == 0:
     print(json.dumps(result))
@@ -725,6 +739,50 @@ def valu_roofline(work, compute, kernel_ms):
   if 'wave_cycle_share' in work:
     out["wave_cycle_share"] = work['wave_cycle_share']
   return out
+
+
+def check_collective_logs(rank, world):
+  """--dry-run: gather every rank's log of collectives and check what a hang or a shape error on a real node would
+  come from: the ranks issue the SAME sequence of operations; symmetric collectives (equal-split all-to-all,
+  reduce-scatter, all-gather, all-reduce) carry identical shapes and dtypes on every rank; for the unequal-split
+  all-to-all of the probes, rank r's send split to s equals rank s's receive split from r."""
+  import torch.distributed as dist
+  from taichi_splatting_amd import distributed as dist_mod
+  logs = [None] * world
+  dist.all_gather_object(logs, dist_mod.collective_log)
+  if rank != 0:
+    return None
+  problems = []
+  lengths = [len(l) for l in logs]
+  if len(set(lengths)) != 1:
+    problems.append(f"ranks issued different numbers of collectives: {lengths}")
+  for i in range(min(lengths)):
+    ops = [l[i][0] for l in logs]
+    if len(set(ops)) != 1:
+      problems.append(f"call {i}: operations differ across ranks: {ops}")
+      continue
+    entries = [l[i] for l in logs]
+    splits = entries[0][2].get('send_splits')
+    if splits is None:
+      if any(e[1] != entries[0][1] for e in entries):
+        problems.append(f"call {i} ({ops[0]}): shapes / dtypes differ across ranks: {[e[1] for e in entries]}")
+    else:
+      for r in range(world):
+        for s_ in range(world):
+          if entries[r][2]['send_splits'][s_] != entries[s_][2]['recv_splits'][r]:
+            problems.append(f"call {i} (all_to_all_single): rank {r} sends {entries[r][2]['send_splits'][s_]} rows to {s_}, "
+                            f"which expects {entries[s_][2]['recv_splits'][r]}")
+      if any(e[1][0][0][1:] != entries[0][1][0][0][1:] or e[1][0][1] != entries[0][1][0][1] for e in entries):
+        problems.append(f"call {i} (all_to_all_single): row width / dtype differ across ranks")
+  from collections import Counter
+  summary = Counter(e[0] for e in logs[0])
+  per_step = {}
+  for op, tensors, extra in logs[0]:
+    key = f"{op} {tensors[0][0] if tensors else ()} {tensors[0][1] if tensors else ''}"
+    per_step[key] = per_step.get(key, 0) + 1
+  assert not problems, "dry run: the ranks' collectives do not line up:\n  " + "\n  ".join(problems[:20])
+  return {"ranks": world, "collectives_issued_by_rank0": dict(summary), "distinct_calls_rank0": per_step,
+          "sequences_match": True, "splits_pair_up": True}
 
 
 def graph_step_ms_in_child(args):

@@ -225,10 +225,47 @@ def expand_routes(first: torch.Tensor, copies: torch.Tensor, total: int):
   return idx[order], dest
 
 
+# ---- what the collectives of a step look like, for dry runs ---------------------------------------------------------
+# `bench.py --dry-run --gpus N` runs the N-rank code path with N processes of a `gloo` group sharing ONE GPU (RCCL
+# itself needs one device per rank): every collective below then stages its device tensors through host memory, and —
+# when `collective_log` is a list — notes (operation, shapes, dtypes, split lists) exactly as the RCCL call would get
+# them, so that the ranks' call sequences can be compared before a real 8-GPU node ever runs them.
+collective_log = None
+
+
+def host_group(group=None) -> bool:
+  """True when the process group has no device collectives (gloo): device tensors are staged through the host."""
+  return dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'gloo'
+
+
+def note_collective(op: str, *tensors, **extra):
+  if collective_log is not None:
+    collective_log.append((op, [(tuple(t.shape), str(t.dtype).replace('torch.', '')) for t in tensors],
+                           {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in extra.items()}))
+
+
+def all_reduce_any(t: torch.Tensor, op=None, group=None):
+  """dist.all_reduce in place, through the host for a gloo group"""
+  op = dist.ReduceOp.SUM if op is None else op
+  note_collective('all_reduce', t, reduce_op=str(op))
+  if t.is_cuda and host_group(group):
+    h = t.cpu()
+    dist.all_reduce(h, op=op, group=group)
+    t.copy_(h)
+  else:
+    dist.all_reduce(t, op=op, group=group)
+
+
 def _all_to_all(send: torch.Tensor, send_counts, recv_counts, group) -> torch.Tensor:
   """``recv`` = rows received from every rank, grouped by source rank (RCCL all-to-all: unequal splits)."""
   recv = send.new_empty((int(sum(recv_counts)),) + tuple(send.shape[1:]))
   if dist.is_available() and dist.is_initialized():
+    note_collective('all_to_all_single', recv, send, recv_splits=list(recv_counts), send_splits=list(send_counts))
+    if send.is_cuda and host_group(group):
+      h = torch.empty(recv.shape, dtype=recv.dtype)
+      dist.all_to_all_single(h, send.contiguous().cpu(), list(recv_counts), list(send_counts), group=group)
+      recv.copy_(h)
+      return recv
     dist.all_to_all_single(recv, send.contiguous(), list(recv_counts), list(send_counts), group=group)
   else:
     assert list(send_counts) == list(recv_counts)
@@ -514,7 +551,7 @@ def overlap_balanced_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, in
   diff.index_add_(0, hi.to(torch.int64), -weight.float())
   hist = torch.cumsum(diff, 0)[:tiles_high]
   if all_reduce and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-    dist.all_reduce(hist, group=group)
+    all_reduce_any(hist, group=group)
   return strip_bounds(tiles_high, world_size, hist.clamp(min=0).tolist())
 
 
@@ -527,5 +564,5 @@ def balanced_strip_bounds(gaussians2d: torch.Tensor, image_size: Tuple[int, int]
   row = torch.floor(gaussians2d[:, 1].detach() / ts).clamp(0, tiles_high - 1).to(torch.int64)
   hist = torch.bincount(row, minlength=tiles_high).to(torch.float32)
   if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-    dist.all_reduce(hist, group=group)
+    all_reduce_any(hist, group=group)
   return strip_bounds(tiles_high, world_size, hist.tolist())

@@ -36,7 +36,14 @@ from .perspective import CameraParams
 def _exchange_all_to_all(recv: torch.Tensor, send: torch.Tensor, group):
   """equal-split all-to-all (RCCL: point-to-point sends over the xGMI links); a copy on one rank"""
   if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-    dist.all_to_all_single(recv, send, group=group)
+    from . import distributed
+    distributed.note_collective('all_to_all_single', recv, send)
+    if send.is_cuda and distributed.host_group(group):          # gloo (dry runs, tests): through host memory
+      h = torch.empty(recv.shape, dtype=recv.dtype)
+      dist.all_to_all_single(h, send.cpu(), group=group)
+      recv.copy_(h)
+    else:
+      dist.all_to_all_single(recv, send, group=group)
   else:
     recv.copy_(send)
 
@@ -267,6 +274,18 @@ class StripStep(_RankStep):
     self.reduce = reduce or self._reduce_scatter_all_gather
 
   def _reduce_scatter_all_gather(self, buf, shard):
+    from . import distributed
+    distributed.note_collective('reduce_scatter_tensor', shard, buf)
+    distributed.note_collective('all_gather_into_tensor', buf, shard)
+    if buf.is_cuda and distributed.host_group(self.group):         # gloo (dry runs, tests): through host memory
+      world = dist.get_world_size(self.group)
+      mine = torch.empty(shard.shape, dtype=shard.dtype)
+      dist.reduce_scatter(mine, list(buf.cpu().chunk(world)), op=dist.ReduceOp.SUM, group=self.group)
+      parts = [torch.empty(shard.shape, dtype=shard.dtype) for _ in range(world)]
+      dist.all_gather(parts, mine, group=self.group)
+      buf.copy_(torch.cat(parts))
+      shard.copy_(mine)
+      return
     dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
     dist.all_gather_into_tensor(buf, shard, group=self.group)
 
@@ -403,9 +422,10 @@ class ShardedStep(_RankStep):
                                                 exchange=exchange or _all_to_all, return_plan=True)
       biggest = torch.tensor([max(plan.send_counts) if plan.send_counts else 0], dtype=torch.int64)
       if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-        if dist.get_backend(self.group) != 'gloo':
+        from . import distributed
+        if not distributed.host_group(self.group):
           biggest = biggest.to(g2d.device)
-        dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
+        distributed.all_reduce_any(biggest, op=dist.ReduceOp.MAX, group=self.group)
       o2p, _ = map_to_tiles_strip(g2, d, self.image_size, self.config, tile_rows=self.rows, ndc_range=self.depth_range)
     self.bucket_capacity = (int(int(biggest.item()) * slack) + 255) // 256 * 256
     self.k_capacity = frame._round_capacity(o2p.shape[0] * slack)
