@@ -322,7 +322,10 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
       sort_pairs_u64_dev_launch(keys, values, keys_sorted, o2p, d.k_capacity, counters + 1, 32, 32 + g.tile_bits,
                                 sk + L.tmp_k, s);
       MS_TRY(find_ranges_u64_dev_launch(keys_sorted, d.k_capacity, counters + 1, g.num_tiles, ranges, s));
-      tile_depth_sort_launch(ranges, g.num_tiles, keys_sorted, o2p, keys, s, counters + 3, in->longest_run_host);
+      // only the strip's tile rows have runs (a rank of 8 would launch 57 344 workgroups that find an empty range)
+      const int64_t first_tile = (int64_t)g.row_begin * g.tiles_wide;
+      const int64_t strip_tiles = (int64_t)(g.row_end > g.row_begin ? g.row_end - g.row_begin : 0) * g.tiles_wide;
+      tile_depth_sort_launch(ranges + 2 * first_tile, strip_tiles, keys_sorted, o2p, keys, s, counters + 3, in->longest_run_host);
     }
   }
   MS_CHECK_LAUNCH();

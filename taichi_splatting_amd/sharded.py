@@ -197,7 +197,21 @@ class _RankStep:
       (g_image,) = torch.autograd.grad(loss, image, allow_unused=True)
     if g_image is None:              # a loss that does not depend on this strip (empty strip): zeros join the collective
       g_image = torch.zeros_like(image)
-    return loss.detach(), g_image.contiguous()
+    return loss.detach(), g_image          # possibly an expanded scalar (sum / mean loss): see _image_grad_pointer
+
+  def _image_grad_pointer(self, gr, g_image, moments_path, row_bytes_f):
+    """dL/dimage for the strip's raster backward.  A sum / mean loss hands autograd an EXPANDED scalar (strides 0): the
+    moments kernel then reads one pixel's values (``grad_image_broadcast``, as render_gaussians does) instead of an
+    (rows, W, f) copy that would be written here and read back there.  Returns the tensor that must stay alive."""
+    broadcast = (frame.BROADCAST_GRAD and moments_path and g_image.dim() == 3 and g_image.shape[0] * g_image.shape[1] > 1
+                 and g_image.stride(0) == 0 and g_image.stride(1) == 0)
+    if broadcast:
+      keep = g_image[0, 0].contiguous()
+      gr.grad_image, gr.grad_image_broadcast = keep.data_ptr(), 1
+    else:
+      keep = g_image.contiguous()
+      gr.grad_image, gr.grad_image_broadcast = keep.data_ptr() - row_bytes_f, 0
+    return keep
 
   def check(self) -> dict:
     """Host read (synchronises the device) of the overflow indicators: the counters of the LAST step, and whether ANY
@@ -347,7 +361,8 @@ class StripStep(_RankStep):
       gc = torch.empty((n, f), dtype=dtype, device=device) if moments_path else torch.zeros((n, f), dtype=dtype, device=device)
     y0 = self.px_rows[0]
     row_bytes = y0 * self.image_size[0] * es
-    gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
+    gr.image = image.data_ptr() - row_bytes * f
+    g_keep = self._image_grad_pointer(gr, g_image, moments_path, row_bytes * f)      # noqa: F841 (alive until the launch)
     gr.stage = _lib.BACKWARD_RASTER
     if in_place:
       gr.grad_points7, gr.grad_colours, gr.boundary_stride = buf.data_ptr(), buf.data_ptr() + 7 * es, width
@@ -512,7 +527,8 @@ class ShardedStep(_RankStep):
     gr = _lib.FrameGradsC()
     moments_path, det = self._raster_backward_mode(lib, desc_b, gr, g_image, device, m)
     row_bytes = self.px_rows[0] * self.image_size[0] * es
-    gr.image, gr.grad_image = image.data_ptr() - row_bytes * f, g_image.data_ptr() - row_bytes * f
+    gr.image = image.data_ptr() - row_bytes * f
+    g_keep = self._image_grad_pointer(gr, g_image, moments_path, row_bytes * f)      # noqa: F841 (alive until the launch)
     gr.stage = _lib.BACKWARD_RASTER
     bw = 7 + f
     if moments_path:

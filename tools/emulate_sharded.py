@@ -55,6 +55,28 @@ class EmulatedExchange:
     self.recv_rows = torch.cat(parts).contiguous()
 
 
+
+# ---- link model (a separate line: the emulation itself charges no link time) ------------------------------------------
+# Every rank has one xGMI link to each of the 7 other GPUs of the node (MI355X_MICROARCH.md: 7 links x ~153 GB/s
+# bidirectional per GPU, i.e. ~64 GB/s usable per link and direction for large messages); LINK_GBS is the sustained
+# one-direction rate this model charges, LAUNCH_US what one RCCL collective costs before its first byte moves.
+LINK_GBS = 50.0
+LAUNCH_US = 20.0
+
+
+def link_model(world, sent_bytes_per_peer_by_collective, compute_ms, single_ms):
+  """sent_bytes_per_peer_by_collective: for each collective of a step, the bytes a rank sends to EACH peer over that
+  peer's own link (all-to-all: its bucket; ring-free reduce-scatter / all-gather over direct links: the peer's shard).
+  All peers' links run in parallel, so a collective takes bytes_per_peer / LINK_GBS + LAUNCH_US."""
+  times = [b / (LINK_GBS * 1e9) * 1e3 + LAUNCH_US * 1e-3 for b in sent_bytes_per_peer_by_collective]
+  total = sum(times)
+  return {"assumes": f"{LINK_GBS:g} GB/s per link and direction, all {world - 1} links of a rank busy at once, {LAUNCH_US:g} us per "
+                     "collective, NOTHING overlapped with compute",
+          "collective_ms": [round(t, 4) for t in times], "link_ms_per_step": round(total, 4),
+          "rank_step_ms_with_links": round(compute_ms + total, 4),
+          "speedup_with_links": round(single_ms / (compute_ms + total), 2)}
+
+
 def main():
   p = argparse.ArgumentParser()
   p.add_argument('--world', type=int, default=8)
@@ -148,6 +170,10 @@ def main():
          "per_rank_ms": per_rank, "max_rank_ms": max(per_rank), "recv_splats": recv,
          "compute_only_speedup": round(t_single / max(per_rank), 2),
          "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
+  f_ch = 3
+  out["exchanged_bytes_per_rank"] = {"forward": W * cap * (9 + f_ch) * 4, "backward": W * cap * (7 + f_ch) * 4,
+                                     "off_chip_fraction": round((W - 1) / W, 3)}
+  out["link_model"] = link_model(W, [cap * (9 + f_ch) * 4, cap * (7 + f_ch) * 4], max(per_rank_graph), t_single)
   emit(args, out)
 
 
@@ -234,6 +260,8 @@ def main_strips(args):
          "collective_bytes_per_rank": {"buffer": rows * 10 * es, "sent_over_xgmi": int(2 * (W - 1) / W * rows * 10 * es)},
          "note": "the cross-rank sum and the xGMI transfers of the reduce-scatter + all-gather are NOT included (device "
                  "copies of the same buffers stand in)"}
+  shard_bytes = rows // W * 10 * es
+  out["link_model"] = link_model(W, [shard_bytes, shard_bytes], max(per_rank_graph), t_single)
   emit(args, out)
 
 
@@ -348,6 +376,10 @@ def main_static(args):
          "compute_only_speedup_graph": round(t_single / max(per_rank_graph), 2),
          "stage_ms_rank0": stages[0],
          "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
+  f_ch = 3
+  out["exchanged_bytes_per_rank"] = {"forward": W * cap * (9 + f_ch) * 4, "backward": W * cap * (7 + f_ch) * 4,
+                                     "off_chip_fraction": round((W - 1) / W, 3)}
+  out["link_model"] = link_model(W, [cap * (9 + f_ch) * 4, cap * (7 + f_ch) * 4], max(per_rank_graph), t_single)
   emit(args, out)
 
 
