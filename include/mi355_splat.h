@@ -247,6 +247,30 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
                                float* grad_points7, float* grad_features, float* point_heuristic,
                                void* stream);
 
+/* Splat rows (round 5; no counterpart in the reference, whose kernels index Gaussian2D.vec and the feature array
+ * separately — rasterizer/forward.py:85-90, backward.py:118-126).  The product raster kernels (float32, F = 3, plain
+ * pdf) can gather each splat from ONE table of MS_SPLAT_ROW floats per point, 64-byte aligned:
+ *   [0..6] the points7 row, [7] free (the frame executor stores the depth), [8..10] the colour, [11..15] unused
+ * — one 128-byte line per gathered splat instead of two or three (config D: backward -6 %, forward -5 %).  A caller
+ * packs the table with ms_splat_rows_pack (depth may be NULL; 0.1 ms for 6 M points) and rasterizes it any number of
+ * times: it pays from the second pass over the same projected gaussians on.  (The frame executor, ms_frame_*, whose
+ * gaussians change every frame, keeps to the dense arrays: filling the table costs it more than the kernels gain;
+ * MS_SPLAT_ROWS=1 in the environment makes it do so for measurements.)  Results
+ * are those of ms_raster_fwd / ms_raster_bwd_moments on the same values: the forward bit for bit, the moments up to
+ * the order of their float atomics (bit for bit with `deterministic`).  ms_raster_moments_finalize is unchanged (it
+ * reads points7).  MS_ERR_UNSUPPORTED for configurations the product kernels do not serve (antialias, no alpha
+ * blending for the forward). */
+#define MS_SPLAT_ROW 16
+int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
+                       void* stream);
+int ms_raster_fwd_rows(const float* rows, const int32_t* tile_ranges, const int32_t* overlap_to_point, int image_w,
+                       int image_h, const ms_raster_config* cfg, float* out_image, float* out_alpha,
+                       float* out_visibility, int tile_row_begin, int tile_row_end, void* stream);
+int ms_raster_bwd_moments_rows(const float* rows, const int32_t* tile_ranges, const int32_t* overlap_to_point,
+                               const float* image, const float* grad_image, int image_w, int image_h,
+                               const ms_raster_config* cfg, float* moments, int deterministic,
+                               const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, void* stream);
+
 /* ---- frame executor --------------------------------------------------------------------------------------------
  * One frame of render_gaussians (renderer.py:23-108) or rasterize (rasterizer/function.py:133-165) as a FIXED launch
  * sequence without host round trips, so that a frame can be enqueued ahead of the GPU and captured in a hipGraph:
@@ -314,6 +338,9 @@ typedef struct ms_frame_layout {
   size_t overlap_to_point;
   /* scratch_k */
   size_t keys, values, keys_sorted, tmp_k;
+  /* keep_n, behind tile_ranges: the splat-row table (64 bytes per gaussian) of a process started with MS_SPLAT_ROWS=1;
+   * 256 unused bytes otherwise */
+  size_t splat_rows;
 } ms_frame_layout;
 
 typedef struct ms_frame_inputs {

@@ -24,6 +24,7 @@ BACKWARD_ALL, BACKWARD_GAUSSIANS, BACKWARD_RASTER = 0, 1, 2   # ms_frame_grads.s
 BOUNDARY_AXIS_SIGMA, BOUNDARY_COVARIANCE = 0, 1
 MAPPER_DIRECT, MAPPER_PRESORT = 0, 1               # ms_frame_grads.boundary_form
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
+SPLAT_ROW = 16    # MS_SPLAT_ROW
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -63,7 +64,8 @@ class FrameLayoutC(ctypes.Structure):
     'points7', 'depth', 'colours', 'points7_f32', 'camera_position', 'counters', 'tile_ranges',
     'sorted_keys', 'order', 'counts', 'cum', 'ordered_points', 'tmp_n',
     'overlap_to_point',
-    'keys', 'values', 'keys_sorted', 'tmp_k')]
+    'keys', 'values', 'keys_sorted', 'tmp_k',
+    'splat_rows')]
 
 
 class FrameInputsC(ctypes.Structure):
@@ -123,6 +125,9 @@ SIGNATURES = {
   'ms_fixed_point_exponents': (c_int, [c_void_p, c_void_p, c_void_p]),
   'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
   'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_splat_rows_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+  'ms_raster_fwd_rows': (c_int, [c_void_p] * 3 + [c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+  'ms_raster_bwd_moments_rows': (c_int, [c_void_p] * 5 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
   'ms_frame_layout_query': (c_int, [POINTER(FrameDescC), POINTER(FrameLayoutC)]),
   'ms_frame_uses_moments': (c_int, [POINTER(FrameDescC), c_int]),
   'ms_frame_project': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p]),

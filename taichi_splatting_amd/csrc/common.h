@@ -45,6 +45,16 @@ static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 // ---- wave64 primitives -------------------------------------------------------------------------
 constexpr int WAVE = 64;
 
+// Splat rows (round 5): ONE 64-byte row per gaussian — [points7 (0..6) | depth (7) | colour (8..10) | unused] — from
+// which the product raster kernels gather a splat with three 16-byte loads out of ONE 128-byte line instead of ten
+// 4-byte loads out of two or three lines (28- and 12-byte rows straddle): config D at tile 16, same box, backward
+// 1.331 -> 1.249 ms, forward 0.626 -> 0.596 ms (tools/rbench.py --rows; 48-byte rows: 1.266 / 0.604; the two arrays
+// merely padded to 32- and 16-byte rows: 1.305 / 0.630 — it is the line count, not the load width).  Offered through
+// the C-ABI (ms_splat_rows_pack, ms_raster_fwd_rows, ms_raster_bwd_moments_rows); the frame executor can fill such a
+// table in its projection and SH kernels but does not by default: see frame.hip, frame_uses_rows.
+constexpr int SPLAT_ROW = 16;
+constexpr int SPLAT_ROW_COLOUR = 8;
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // DPP move: returns src shuffled by the DPP control, lanes without a source keep `old`.

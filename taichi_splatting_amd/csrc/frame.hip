@@ -59,6 +59,19 @@ static int check_desc(const ms_frame_desc* d, const char* who) {
   return 0;
 }
 
+// Splat rows (common.h) inside the frame executor: OFF unless MS_SPLAT_ROWS=1 is in the environment (read once).  The
+// raster kernels gain 0.057 + 0.030 ms on config D from the one-line gathers, but FILLING the table costs the frame
+// more than that: the projection kernel's 32-byte pieces and the SH kernel's 16-byte pieces are partial writes of
+// 64-byte sectors, which HBM serves at ~1.4 TB/s (projection 0.088 -> 0.230 ms, SH 0.243 -> 0.337 ms; frame 3.16 ->
+// 3.37 ms, profiles/r05_splat_rows.txt), and one kernel writing whole rows has to move 0.58 GB more than the frame
+// does today (~0.10 ms).  The table pays where rows arrive complete or are rasterized more than once — the C-ABI
+// entry points ms_splat_rows_pack / ms_raster_fwd_rows / ms_raster_bwd_moments_rows — and stays here as a switch for
+// measurements.
+static bool frame_uses_rows(const ms_frame_desc* d) {
+  static const bool on = [] { const char* e = getenv("MS_SPLAT_ROWS"); return e && e[0] == '1'; }();
+  return on && !d->projected_input && d->n > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype);
+}
+
 struct Carve {
   size_t off = 0;
   size_t take(size_t bytes) { const size_t o = off; off += align_up(bytes > 0 ? bytes : 1, 256); return o; }
@@ -75,6 +88,7 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->camera_position = keep_n.take(4 * g.es);
   L->counters = keep_n.take(8 * sizeof(int32_t));
   L->tile_ranges = keep_n.take((size_t)g.num_tiles * 2 * sizeof(int32_t));
+  L->splat_rows = keep_n.take(frame_uses_rows(d) ? n * SPLAT_ROW * sizeof(float) : 0);
   L->keep_n_bytes = keep_n.off;
 
   L->sorted_keys = scratch_n.take(n * 4);
@@ -183,18 +197,21 @@ static int frame_project_impl(const ms_frame_desc* desc, const ms_frame_inputs* 
     set_error("%s: null gaussian / camera input", who); return MS_ERR_BAD_ARG;
   }
   if (!in->feature) { set_error("%s: feature is null", who); return MS_ERR_BAD_ARG; }
+  float* rows = frame_uses_rows(desc) ? (float*)(kn + L.splat_rows) : nullptr;
   if (projection) {
     // (projection alone = ms_frame_project_count: the camera position is then made by ms_frame_map_raster's prepare
     // kernel, next to the K limit)
     if (d.sh_degree >= 0 && colours)
       MS_TRY(ms_camera_position(in->T_camera_world, kn + L.camera_position, d.dtype, stream));
-    MS_TRY(ms_project_fwd(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
-                          d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
-                          d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream));
+    // (without SH the features ARE the colours: the projection kernel copies them into the rows)
+    MS_TRY(project_fwd_launch(in->position, in->log_scaling, in->rotation, in->alpha_logit, in->T_camera_world, in->projection,
+                              d.image_w, d.image_h, d.near_plane, d.far_plane, d.blur_cov, d.clamp_margin,
+                              d.raster.alpha_threshold, d.n, kn + L.points7, kn + L.depth, nullptr, d.dtype, stream, rows,
+                              rows && d.sh_degree < 0 ? in->feature : nullptr));
   }
   if (colours && d.sh_degree >= 0)
     MS_TRY(sh_fwd_inplace_launch(in->feature, in->position, kn + L.depth, kn + L.camera_position, d.n, d.f,
-                                 d.sh_degree, kn + L.colours, d.dtype, (hipStream_t)stream));
+                                 d.sh_degree, kn + L.colours, d.dtype, (hipStream_t)stream, rows));
   return 0;
 }
 
@@ -333,8 +350,9 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   const void* points7 = d.projected_input ? in->points7 : (const void*)(kn + L.points7);
   const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
   MS_CHECK_ARG(d.n == 0 || colours != nullptr, "colours are null");
-  return ms_raster_fwd(points7, colours, ranges, o2p, d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha,
-                       out_visibility, g.row_begin, g.row_end, d.dtype, stream);
+  return raster_fwd_launch(points7, colours, frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr, ranges, o2p,
+                           d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha, out_visibility, g.row_begin, g.row_end,
+                           d.dtype, stream);
 }
 
 extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
@@ -380,7 +398,8 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
     MS_TRY(raster_bwd_moments_launch(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
                                      (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end,
-                                     gr->grad_image_broadcast, s));
+                                     gr->grad_image_broadcast, s,
+                                     frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr));
     if (raster_only)
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,

@@ -97,11 +97,32 @@ void tile_emit_direct_launch(const float* points7, const void* depth, int dtype,
 void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
                             uint64_t* scratch, hipStream_t s, int32_t* run_stats = nullptr, int32_t* run_host = nullptr);
 
+// ---- projection.hip ---------------------------------------------------------------------------------------------
+// ms_project_fwd; splat_rows (float32): also fills words 0..7 of each gaussian's splat row (common.h) and, when colours_in
+// (n x 3) is given, words 8..11
+int project_fwd_launch(const void* position, const void* log_scaling, const void* rotation, const void* alpha_logit,
+                       const void* T_camera_world, const void* projection, int image_w, int image_h, double near_plane,
+                       double far_plane, double blur_cov, double clamp_margin, double alpha_threshold, int64_t n,
+                       void* out_points7, void* out_depth, int32_t* out_flag, int dtype, void* stream, float* splat_rows,
+                       const void* colours_in);
+
 // ---- sh.hip -----------------------------------------------------------------------------------------------------
 // SH colours of ALL n gaussians in place (identity index list); rows with depth[i] <= 0 (culled) get zeros and
 // their 4 F D parameter bytes are not read
+// splat_rows (float32 RGB only): the colours also go into words 8..10 of each gaussian's splat row (raster_common.h)
 int sh_fwd_inplace_launch(const void* params, const void* positions, const void* depth, const void* cam_pos,
-                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s);
+                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s, float* splat_rows = nullptr);
+
+// ---- raster.hip -------------------------------------------------------------------------------------------------
+// Splat rows (raster_common.h: SPLAT_ROW floats per gaussian, [points7 | depth | colour | 0]): a side table the frame
+// executor's projection and SH kernels fill for the product raster kernels, which then gather one 128-byte line per
+// splat.  The dense arrays stay what every other consumer (mapper, per-gaussian backward, outputs) reads.
+bool raster_uses_splat_rows(const ms_raster_config* cfg, int f, int dtype);
+// ms_raster_fwd; splat_rows != NULL: the product kernels read the table instead of points7 / features
+int raster_fwd_launch(const void* points7, const void* features, const float* splat_rows, const int32_t* tile_ranges,
+                      const int32_t* overlap_to_point, int image_w, int image_h, int f, const ms_raster_config* cfg,
+                      void* out_image, void* out_alpha, void* out_visibility, int tile_row_begin, int tile_row_end,
+                      int dtype, void* stream);
 
 // ---- raster_bwd_scan.hip ----------------------------------------------------------------------------------------
 // ms_raster_bwd_moments with grad_broadcast: dL/dimage given as ONE pixel's f values (ms_frame_grads.grad_image_broadcast)
@@ -109,7 +130,7 @@ int raster_bwd_moments_launch(const void* points7, const void* features, const i
                               const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
                               int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
                               const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
-                              hipStream_t s);
+                              hipStream_t s, const float* splat_rows = nullptr);
 // ms_raster_moments_finalize that also clears the rows it reads (persistent moments buffer)
 // row_stride > 0: grad_points7 / grad_features are columns of one row-major array with that many floats per row
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,

@@ -26,7 +26,8 @@ project_fwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
                    const T* __restrict__ rotation, const T* __restrict__ alpha_logit,
                    const T* __restrict__ Tcw, const T* __restrict__ proj, ProjParams<T> pp,
                    int64_t n, T* __restrict__ out_points, T* __restrict__ out_depth,
-                   int32_t* __restrict__ out_flag) {
+                   int32_t* __restrict__ out_flag, float* __restrict__ splat_rows = nullptr,
+                   const T* __restrict__ colours_in = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
 
@@ -47,6 +48,16 @@ project_fwd_kernel(const T* __restrict__ position, const T* __restrict__ log_sca
   o[6] = st.alpha;
   out_depth[i] = in_view ? st.pc[2] : T(0);
   if (out_flag) out_flag[i] = in_view ? 1 : 0;
+  // frame executor (float32 RGB): the gaussian's splat row (common.h) — the same seven values and the depth; the
+  // colour words are the SH kernel's, or copied here when the features ARE the colours (colours_in)
+  if constexpr (sizeof(T) == 4) {
+    if (splat_rows) {
+      float4* row = reinterpret_cast<float4*>(splat_rows + i * SPLAT_ROW);
+      row[0] = float4{st.uv[0], st.uv[1], st.axis[0], st.axis[1]};
+      row[1] = float4{st.sigma[0], st.sigma[1], st.alpha, in_view ? st.pc[2] : 0.0f};
+      if (colours_in) row[2] = float4{colours_in[i * 3 + 0], colours_in[i * 3 + 1], colours_in[i * 3 + 2], 0.0f};
+    }
+  }
 }
 
 template <typename T>
@@ -134,8 +145,22 @@ extern "C" int ms_project_fwd(const void* position, const void* log_scaling, con
                               double far_plane, double blur_cov, double clamp_margin,
                               double alpha_threshold, int64_t n, void* out_points7, void* out_depth,
                               int32_t* out_flag, int dtype, void* stream) {
+  return project_fwd_launch(position, log_scaling, rotation, alpha_logit, T_camera_world, projection, image_w, image_h,
+                            near_plane, far_plane, blur_cov, clamp_margin, alpha_threshold, n, out_points7, out_depth,
+                            out_flag, dtype, stream, nullptr, nullptr);
+}
+
+// ms_project_fwd; splat_rows (float32 only): also fills words 0..7 of every gaussian's splat row, and words 8..11 from
+// colours_in (n x 3) when given
+int ms::project_fwd_launch(const void* position, const void* log_scaling, const void* rotation,
+                           const void* alpha_logit, const void* T_camera_world,
+                           const void* projection, int image_w, int image_h, double near_plane,
+                           double far_plane, double blur_cov, double clamp_margin,
+                           double alpha_threshold, int64_t n, void* out_points7, void* out_depth,
+                           int32_t* out_flag, int dtype, void* stream, float* splat_rows, const void* colours_in) {
   MS_CHECK_ARG(n >= 0, "n < 0");
   MS_CHECK_ARG(dtype == MS_F32 || dtype == MS_F64, "dtype must be MS_F32 or MS_F64");
+  MS_CHECK_ARG(!splat_rows || dtype == MS_F32, "splat rows are float32");
   if (n == 0) return 0;
   MS_CHECK_ARG(position && log_scaling && rotation && alpha_logit && T_camera_world && projection,
                "null input");
@@ -147,7 +172,7 @@ extern "C" int ms_project_fwd(const void* position, const void* log_scaling, con
         (const float*)position, (const float*)log_scaling, (const float*)rotation,
         (const float*)alpha_logit, (const float*)T_camera_world, (const float*)projection,
         make_params<float>(image_w, image_h, near_plane, far_plane, blur_cov, clamp_margin, alpha_threshold),
-        n, (float*)out_points7, (float*)out_depth, out_flag);
+        n, (float*)out_points7, (float*)out_depth, out_flag, splat_rows, (const float*)colours_in);
   } else {
     project_fwd_kernel<double><<<grid, block, 0, s>>>(
         (const double*)position, (const double*)log_scaling, (const double*)rotation,

@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "raster_common.h"
+#include "frame_internal.h"
 
 namespace ms {
 
@@ -563,7 +564,7 @@ using namespace ms;
 // product-path kernels (float, F = 3, plain pdf, blending): raster_fast.hip
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
-                        int row_begin, int num_tiles, hipStream_t s);
+                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows);
 bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
@@ -592,6 +593,61 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
                              const ms_raster_config* cfg, void* out_image, void* out_alpha,
                              void* out_visibility, int tile_row_begin, int tile_row_end, int dtype,
                              void* stream) {
+  return raster_fwd_launch(points7, features, nullptr, tile_ranges, overlap_to_point, image_w, image_h, f, cfg, out_image,
+                           out_alpha, out_visibility, tile_row_begin, tile_row_end, dtype, stream);
+}
+
+namespace ms {
+__global__ void __launch_bounds__(256)
+splat_rows_pack_kernel(const float* __restrict__ points, const float* __restrict__ depth, const float* __restrict__ colours,
+                       int64_t n, float* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* g = points + i * 7;
+  float4* row = reinterpret_cast<float4*>(rows + i * SPLAT_ROW);
+  row[0] = float4{g[0], g[1], g[2], g[3]};
+  row[1] = float4{g[4], g[5], g[6], depth ? depth[i] : 0.0f};
+  row[2] = float4{colours[i * 3 + 0], colours[i * 3 + 1], colours[i * 3 + 2], 0.0f};
+}
+}  // namespace ms
+
+static_assert(MS_SPLAT_ROW == ms::SPLAT_ROW, "include/mi355_splat.h and common.h disagree on the splat row");
+
+extern "C" int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
+                                  void* stream) {
+  MS_CHECK_ARG(n >= 0, "n < 0");
+  if (n == 0) return 0;
+  MS_CHECK_ARG(points7 && colours3 && rows, "null pointer");
+  MS_CHECK_ARG((reinterpret_cast<uintptr_t>(rows) & 63) == 0, "rows must be 64-byte aligned");
+  splat_rows_pack_kernel<<<dim3((unsigned)div_up(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(points7, depth, colours3, n, rows);
+  MS_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int ms_raster_fwd_rows(const float* rows, const int32_t* tile_ranges, const int32_t* overlap_to_point,
+                                  int image_w, int image_h, const ms_raster_config* cfg, float* out_image,
+                                  float* out_alpha, float* out_visibility, int tile_row_begin, int tile_row_end,
+                                  void* stream) {
+  MS_CHECK_ARG(cfg && rows, "null pointer");
+  if (!raster_uses_splat_rows(cfg, 3, MS_F32)) {
+    set_error("ms_raster_fwd_rows: splat rows serve float32 RGB, plain pdf, alpha blending, tile 8 / 16 / 32");
+    return MS_ERR_UNSUPPORTED;
+  }
+  return raster_fwd_launch(rows, rows, rows, tile_ranges, overlap_to_point, image_w, image_h, 3, cfg, out_image, out_alpha,
+                           out_visibility, tile_row_begin, tile_row_end, MS_F32, stream);
+}
+
+bool ms::raster_uses_splat_rows(const ms_raster_config* cfg, int f, int dtype) {
+  return dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending &&
+         (cfg->tile_size == 8 || cfg->tile_size == 16 || cfg->tile_size == 32);
+}
+
+// ms_raster_fwd with the frame executor's splat-row table (frame_internal.h): the product kernels gather from it when
+// the configuration is theirs (raster_uses_splat_rows), everything else reads the dense arrays as before
+int ms::raster_fwd_launch(const void* points7, const void* features, const float* splat_rows, const int32_t* tile_ranges,
+                      const int32_t* overlap_to_point, int image_w, int image_h, int f, const ms_raster_config* cfg,
+                      void* out_image, void* out_alpha, void* out_visibility, int tile_row_begin, int tile_row_end,
+                      int dtype, void* stream) {
   int rc = check_raster_common(cfg, image_w, image_h, f, dtype, &tile_row_begin, &tile_row_end, "ms_raster_fwd");
   if (rc) return rc;
   MS_CHECK_ARG(tile_ranges && out_image && out_alpha, "null pointer");
@@ -602,7 +658,7 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
   if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending) {
     void* vis = (cfg->compute_visibility && out_visibility) ? out_visibility : nullptr;
     if (ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                           out_alpha, vis, tile_row_begin, num_tiles, s)) {
+                           out_alpha, vis, tile_row_begin, num_tiles, s, splat_rows)) {
       MS_CHECK_LAUNCH();
       return 0;
     }

@@ -141,7 +141,7 @@ __global__ void fixed_point_exponents_kernel(const float* __restrict__ amax, int
 // Four waves per SIMD (<= 128 VGPRs) is what the 40 KB of LDS per tile-16 workgroup allow, and the kernel is written
 // to that budget; without the bound the register allocator of ROCm 7.2 lets the tile-16 instantiation drift to 137
 // registers, i.e. three waves (tile 8 is LDS-bound at three waves per SIMD whatever it uses).
-template <int TS, bool HEUR, int SPLIT = 1>
+template <int TS, bool HEUR, int SPLIT = 1, bool ROWS = false>      // ROWS: `points` = splat-row table (raster_common.h)
 __global__ void __launch_bounds__(TS * TS, TS == 8 ? 1 : 4)
 raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
@@ -279,8 +279,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   auto b_load = [&](int id, int j) {
     const uint64_t pa = reinterpret_cast<uint64_t>(points), fa = reinterpret_cast<uint64_t>(feats),
                    oa = reinterpret_cast<uint64_t>(o2p);
-    const uint64_t a_geom = pa + 4ull * (uint64_t)((int64_t)id * 7 + (b_geom ? b_comp : 0));
-    const uint64_t a_col = fa + 4ull * (uint64_t)((int64_t)id * 3 + (b_col ? b_comp - 7 : 0));
+    const int g_row = ROWS ? SPLAT_ROW : 7, c_row = ROWS ? SPLAT_ROW : 3, c_off = ROWS ? SPLAT_ROW_COLOUR : 0;
+    const uint64_t a_geom = pa + 4ull * (uint64_t)((int64_t)id * g_row + (b_geom ? b_comp : 0));
+    const uint64_t a_col = (ROWS ? pa : fa) + 4ull * (uint64_t)((int64_t)id * c_row + c_off + (b_col ? b_comp - 7 : 0));
     const uint64_t a_id = oa + 4ull * (uint64_t)list_pos(j, b_slot);
     uint64_t addr = b_geom ? a_geom : (b_col ? a_col : a_id);
     asm volatile("" : "+v"(addr));          // (one load, whatever the component; nothing here is loop invariant)
@@ -297,7 +298,10 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // batch + 3
   auto stage_next = [&](int batch) {
     if (!PIPELINED) return;
-    rec = make_scan_record(raw, rp.alpha_threshold); rec_id = raw.id;
+    // (a tile of three batches passes five stage points; the record of a batch that does not exist is not computed —
+    // a wave-uniform branch whose both sides define every register of the record, so that nothing lives across it)
+    if (batch + 1 >= 0 && batch + 1 < num_batches) { rec = make_scan_record(raw, rp.alpha_threshold); rec_id = raw.id; }
+    else { rec = ScanRecord{}; rec_id = 0; }
     // the record is finished before the gathers are issued: they then load straight into the registers of `raw`.  Left
     // to itself the scheduler hoists the loads above the record arithmetic, lands them in fresh registers and copies
     // them home at the loop latch — behind the commit, i.e. with a wait for every atomic of the commit again.
@@ -308,7 +312,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
     // next id then lands in next_id's register instead of a fresh one that is copied over behind the commit)
     int gather_id;
     asm volatile("v_mov_b32 %0, %1" : "=v"(gather_id) : "v"(next_id));
-    raw = load_raw(points, feats, gather_id);
+    raw = load_raw<ROWS>(points, feats, gather_id);
     next_id = o2p[list_pos(batch + 3, t)];
     if (SLOTS_B > 0) {
       asm volatile("v_mov_b32 %0, %1" : "=v"(b_hold) : "v"(b_val));       // the gathered component is consumed HERE
@@ -426,7 +430,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       }
     } else {
       for (int s = t; s < count; s += THREADS) {
-        const Raw r = load_raw(points, feats, o2p[begin + s]);
+        const Raw r = load_raw<ROWS>(points, feats, o2p[begin + s]);
         write_scan_record(r, rp.alpha_threshold, &s_rec[s * 3]);
         s_id[s] = r.id;
       }
@@ -872,7 +876,8 @@ static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
                                 float* moments, int deterministic, const int32_t* fixed_exp, int tile_row_begin,
-                                int tile_row_end, hipStream_t s, const char* who, int grad_broadcast = 0) {
+                                int tile_row_end, hipStream_t s, const char* who, int grad_broadcast = 0,
+                                const float* splat_rows = nullptr) {
   if (deterministic && !fixed_exp) { set_error("%s: deterministic commits need fixed_exp (ms_fixed_point_exponents)", who); return MS_ERR_BAD_ARG; }
   if (image_w <= 0 || image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
   if (!cfg->use_alpha_blending) {
@@ -895,11 +900,13 @@ static int launch_scan_backward(const float* points7, const float* features,
   rp.deterministic = deterministic != 0;
   rp.grad_broadcast = grad_broadcast != 0;
   rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
-#define MS_GO(TS, HEUR, SPLIT) raster_bwd_scan_kernel<TS, HEUR, SPLIT>                                           \
+#define MS_GO(TS, HEUR, SPLIT, ROWS) raster_bwd_scan_kernel<TS, HEUR, SPLIT, ROWS>                               \
       <<<dim3(xcd_grid<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, SPLIT * SPLIT)), dim3(TS * TS), 0, s>>>(              \
-          points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp)
-#define MS_GO_TILE(TS, SPLIT)                                                                                   \
-  do { if (hf) MS_GO(TS, true, SPLIT); else MS_GO(TS, false, SPLIT); } while (0)
+          ROWS ? splat_rows : points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp)
+#define MS_GO_TILE(TS, SPLIT, ROWS)                                                                             \
+  do { if (hf) MS_GO(TS, true, SPLIT, ROWS); else MS_GO(TS, false, SPLIT, ROWS); } while (0)
+  // the splat-row table serves the one-workgroup-per-tile kernels of tile 16 and 32 (tile 8 gathers inside its pass
+  // loop and measured 10 % SLOWER with the 16-byte loads; the quarter-tile variant is a fallback)
   const bool hf = cfg->compute_point_heuristic;
 #ifdef MS_WITH_ROWS_KERNEL      // tools/experiments/raster_bwd_rows.hip (measured and dropped in round 4)
   if (launch_rows_backward(points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, ts, hf, moments,
@@ -909,12 +916,14 @@ static int launch_scan_backward(const float* points7, const float* features,
   }
 #endif
   switch (ts) {
-    case 8: MS_GO_TILE(8, 1); break;
-    case 16: MS_GO_TILE(16, 1); break;
+    case 8: MS_GO_TILE(8, 1, false); break;
+    case 16: if (splat_rows) MS_GO_TILE(16, 1, true); else MS_GO_TILE(16, 1, false); break;
     default:
       // tile 32: ONE 1024-thread workgroup per tile with 896-splat batches (152 KB LDS), or — MS_TILE32_BWD=quarters —
       // four 16 x 16 quarter workgroups per tile that each stage the whole tile list
-      if (tile32_quarters()) MS_GO_TILE(16, 2); else MS_GO_TILE(32, 1);
+      if (tile32_quarters()) MS_GO_TILE(16, 2, false);
+      else if (splat_rows) MS_GO_TILE(32, 1, true);
+      else MS_GO_TILE(32, 1, false);
       break;
   }
 #undef MS_GO_TILE
@@ -933,6 +942,22 @@ extern "C" int ms_raster_bwd_moments(const void* points7, const void* features, 
                               (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
                               deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
                               "ms_raster_bwd_moments");
+}
+
+extern "C" int ms_raster_bwd_moments_rows(const float* rows, const int32_t* tile_ranges, const int32_t* overlap_to_point,
+                                          const float* image, const float* grad_image, int image_w, int image_h,
+                                          const ms_raster_config* cfg, float* moments, int deterministic,
+                                          const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && rows && tile_ranges && image && grad_image && moments, "null pointer");
+  // (tile 8 and the quarter-tile variant of tile 32 gather row by row from the same table: points7 at stride
+  // MS_SPLAT_ROW is not what their dense loads expect, so they are not offered here)
+  if (cfg->tile_size == 8 || (cfg->tile_size == 32 && tile32_quarters())) {
+    set_error("ms_raster_bwd_moments_rows: tile 16, or tile 32 with one workgroup per tile");
+    return MS_ERR_UNSUPPORTED;
+  }
+  return launch_scan_backward(rows, rows, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg, moments,
+                              deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
+                              "ms_raster_bwd_moments_rows", 0, rows);
 }
 
 extern "C" int ms_fixed_point_exponents(const float* amax_dev, int32_t* out_exp2, void* stream) {
@@ -985,10 +1010,11 @@ int raster_bwd_moments_launch(const void* points7, const void* features, const i
                               const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
                               int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
                               const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
-                              hipStream_t s) {
+                              hipStream_t s, const float* splat_rows) {
   return launch_scan_backward((const float*)points7, (const float*)features, tile_ranges, overlap_to_point,
                               (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
-                              deterministic, fixed_exp, tile_row_begin, tile_row_end, s, "ms_frame_backward", grad_broadcast);
+                              deterministic, fixed_exp, tile_row_begin, tile_row_end, s, "ms_frame_backward", grad_broadcast,
+                              splat_rows);
 }
 
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,

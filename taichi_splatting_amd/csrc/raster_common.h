@@ -54,14 +54,23 @@ struct Raw {
   int id;
 };
 
+// (ROWS: the frame executor's splat-row table, common.h)
+template <bool ROWS = false>
 __device__ __forceinline__ Raw load_raw(const float* __restrict__ points, const float* __restrict__ feats, int id) {
   Raw r;
-  const float* g = points + (int64_t)id * 7;
-  const float* f = feats + (int64_t)id * 3;
+  if constexpr (ROWS) {
+    const float4* row = reinterpret_cast<const float4*>(points) + (int64_t)id * (SPLAT_ROW / 4);
+    const float4 a = row[0], b = row[1], c = row[2];
+    r.g[0] = a.x; r.g[1] = a.y; r.g[2] = a.z; r.g[3] = a.w; r.g[4] = b.x; r.g[5] = b.y; r.g[6] = b.z;
+    r.f[0] = c.x; r.f[1] = c.y; r.f[2] = c.z;
+  } else {
+    const float* g = points + (int64_t)id * 7;
+    const float* f = feats + (int64_t)id * 3;
 #pragma unroll
-  for (int k = 0; k < 7; ++k) r.g[k] = g[k];
+    for (int k = 0; k < 7; ++k) r.g[k] = g[k];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) r.f[k] = f[k];
+    for (int k = 0; k < 3; ++k) r.f[k] = f[k];
+  }
   r.id = id;
   return r;
 }

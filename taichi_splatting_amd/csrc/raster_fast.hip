@@ -36,7 +36,7 @@ constexpr float FWD_SPENT_T = 1.3552527e-20f;   // 2^-66: transmittance below wh
 constexpr unsigned FWD_XCD_CHUNK = 8;      // tiles per XCD run (xcd_tile, raster_common.h)
 constexpr unsigned BWD_XCD_CHUNK = 8;      // pixel-per-lane backward: 3.12 -> 3.08 ms at tile 32, 2.84 -> 2.79 at tile 16
 
-template <int TS, bool VIS>
+template <int TS, bool VIS, bool ROWS>       // ROWS: `points` is the frame's splat-row table (raster_common.h), `feats` unused
 __global__ void __launch_bounds__(TS * TS)
 raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                         const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
@@ -76,7 +76,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   Raw raw;
   int next_id = 0;
   const bool stager = t < BATCH;
-  if (stager && start + t < end) raw = load_raw(points, feats, o2p[start + t]);
+  if (stager && start + t < end) raw = load_raw<ROWS>(points, feats, o2p[start + t]);
   if (stager && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
 
   for (int begin = start; begin < end; begin += BATCH) {
@@ -100,7 +100,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2], origin_x, origin_y);
       if (VIS) s_id[t] = raw.id;
     }
-    if (stager && begin + BATCH + t < end) raw = load_raw(points, feats, next_id);
+    if (stager && begin + BATCH + t < end) raw = load_raw<ROWS>(points, feats, next_id);
     if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
     __syncthreads();
     if (wave_spent) continue;
@@ -355,15 +355,17 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
 // Called from raster.hip's dispatch.  Returns true if the fast path handled the launch.
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
-                        int row_begin, int num_tiles, hipStream_t s) {
+                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows) {
   const FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
   const dim3 grid(xcd_grid<FWD_XCD_CHUNK>(rp.num_tiles, 1));
+#define MS_GO3(TS, VIS, ROWS)                                                                                   \
+  raster_fwd_f32x3_kernel<TS, VIS, ROWS><<<grid, dim3(TS * TS), 0, s>>>(                                        \
+      ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha,  \
+      VIS ? (float*)visibility : nullptr)
 #define MS_GO(TS)                                                                                               \
   do {                                                                                                          \
-    if (visibility) raster_fwd_f32x3_kernel<TS, true><<<grid, dim3(TS * TS), 0, s>>>(                           \
-        (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, (float*)visibility); \
-    else raster_fwd_f32x3_kernel<TS, false><<<grid, dim3(TS * TS), 0, s>>>(                                     \
-        (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, nullptr);     \
+    if (splat_rows) { if (visibility) MS_GO3(TS, true, true); else MS_GO3(TS, false, true); }                   \
+    else { if (visibility) MS_GO3(TS, true, false); else MS_GO3(TS, false, false); }                            \
   } while (0)
   switch (cfg->tile_size) {
     case 8: MS_GO(8); return true;
@@ -371,6 +373,7 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
     case 32: MS_GO(32); return true;
   }
 #undef MS_GO
+#undef MS_GO3
   return false;
 }
 

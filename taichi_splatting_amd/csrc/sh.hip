@@ -19,14 +19,18 @@ template <typename T, int DEG>
 __global__ void __launch_bounds__(256)
 sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
               const int64_t* __restrict__ indexes, const T* __restrict__ cam_pos, int64_t v, int f,
-              T* __restrict__ out, const T* __restrict__ cull_depth = nullptr) {
+              T* __restrict__ out, const T* __restrict__ cull_depth = nullptr, float* __restrict__ splat_rows = nullptr) {
   constexpr int D = (DEG + 1) * (DEG + 1);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= v) return;
+  // frame executor, float32 RGB: the colour also goes into the gaussian's splat row (raster_common.h)
+  float* row = nullptr;
+  if constexpr (sizeof(T) == 4) { if (splat_rows) row = splat_rows + i * SPLAT_ROW + SPLAT_ROW_COLOUR; }
   // frame executor: indexes == NULL is the identity list over ALL gaussians; culled ones (depth <= 0) get zeros
   // without touching their parameter row
   if (cull_depth && !(cull_depth[i] > T(0))) {
     for (int c = 0; c < f; ++c) out[i * f + c] = T(0);
+    if (row) *reinterpret_cast<float4*>(row) = float4{0.f, 0.f, 0.f, 0.f};
     return;
   }
   const int64_t idx = indexes ? indexes[i] : i;
@@ -43,8 +47,11 @@ sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
     T acc = T(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) acc += Y[d] * p[c * D + d];
-    out[i * f + c] = t_clamp(acc + T(0.5), T(0), T(1));
+    const T colour = t_clamp(acc + T(0.5), T(0), T(1));
+    out[i * f + c] = colour;
+    if (row) row[c] = (float)colour;
   }
+  if (row) row[3] = 0.0f;
 }
 
 // Frame executor, float32 RGB degree 3 (the headline configuration): the parameter rows of a wave's 64 consecutive
@@ -60,7 +67,7 @@ sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
 __global__ void __launch_bounds__(256)
 sh_fwd_rows_deg3_kernel(const float* __restrict__ params, const float* __restrict__ positions,
                         const float* __restrict__ cam_pos, const float* __restrict__ cull_depth, int64_t n,
-                        float* __restrict__ out) {
+                        float* __restrict__ out, float* __restrict__ splat_rows) {
   constexpr int D = 16, PIECES = 12, YS = 20;      // YS: 16-byte aligned rows, 4 lanes apart never on the same banks
   typedef float vec4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) float s_Y[4][64 * YS];
@@ -104,11 +111,23 @@ sh_fwd_rows_deg3_kernel(const float* __restrict__ params, const float* __restric
       acc += dpp_f32<0xB1>(0.f, acc);                   // quad_perm:[1,0,3,2]
       acc += dpp_f32<0x4E>(0.f, acc);                   // quad_perm:[2,3,0,1]
       // q / 4 = 3 j + c: the quad's first lane writes colour c of gaussian j (0 for a culled one, sh_fwd_kernel's)
-      if ((lane & 3) == 0 && j < count) dst[q >> 2] = on ? t_clamp(acc + 0.5f, 0.0f, 1.0f) : 0.0f;
+      if ((lane & 3) == 0 && j < count) {
+        const float colour = on ? t_clamp(acc + 0.5f, 0.0f, 1.0f) : 0.0f;
+        dst[q >> 2] = colour;
+        // splat rows: the colour goes through the four spare words of the gaussian's LDS row (k >> 2 = channel) so that
+        // its lane stores ONE 16-byte piece behind the barrier below (three scattered dwords per row cost the frame more
+        // than the raster kernels gain)
+        if (splat_rows) s_Y[wave][j * YS + D + (k >> 2)] = colour;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (splat_rows && lane < count) {
+      vec4 c = *reinterpret_cast<const vec4*>(&s_Y[wave][lane * YS + D]);
+      c.w = 0.0f;
+      *reinterpret_cast<vec4*>(splat_rows + i * SPLAT_ROW + SPLAT_ROW_COLOUR) = c;
+    }
   }
 }
 
@@ -298,10 +317,10 @@ static int launch_sh_bwd(const void* params, const void* positions, const int64_
 
 template <typename T>
 static void launch_sh_fwd_inplace(const void* params, const void* positions, const void* depth, const void* cam,
-                                  int64_t n, int f, int degree, void* out, hipStream_t s) {
+                                  int64_t n, int f, int degree, void* out, hipStream_t s, float* splat_rows) {
   const dim3 block(256), grid((unsigned)div_up(n, 256));
 #define MS_SH_FWD(DEG) \
-  sh_fwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, nullptr, (const T*)cam, n, f, (T*)out, (const T*)depth)
+  sh_fwd_kernel<T, DEG><<<grid, block, 0, s>>>((const T*)params, (const T*)positions, nullptr, (const T*)cam, n, f, (T*)out, (const T*)depth, splat_rows)
   switch (degree) {
     case 0: MS_SH_FWD(0); break;
     case 1: MS_SH_FWD(1); break;
@@ -312,19 +331,20 @@ static void launch_sh_fwd_inplace(const void* params, const void* positions, con
 }
 
 int sh_fwd_inplace_launch(const void* params, const void* positions, const void* depth, const void* cam_pos,
-                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s) {
+                          int64_t n, int f, int degree, void* out, int dtype, hipStream_t s, float* splat_rows) {
   if (n == 0) return 0;
+  if (splat_rows && !(dtype == MS_F32 && f == 3)) { set_error("sh_fwd_inplace_launch: splat rows are float32 RGB"); return MS_ERR_BAD_ARG; }
   static const bool rows_off = [] { const char* e = getenv("MS_SH_FWD"); return e && e[0] == 'w'; }();   // "walk": the per-lane row walk
   if (dtype == MS_F32 && f == 3 && degree == 3 && !rows_off && (reinterpret_cast<uintptr_t>(params) & 15) == 0) {
     int64_t blocks = div_up(n, 256);
     if (blocks > MS_SH_ROWS_BLOCKS) blocks = MS_SH_ROWS_BLOCKS;       // grid-stride: a resident grid streams best
     sh_fwd_rows_deg3_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const float*)params, (const float*)positions,
                                                                         (const float*)cam_pos, (const float*)depth, n,
-                                                                        (float*)out);
+                                                                        (float*)out, splat_rows);
     return 0;
   }
-  if (dtype == MS_F32) launch_sh_fwd_inplace<float>(params, positions, depth, cam_pos, n, f, degree, out, s);
-  else launch_sh_fwd_inplace<double>(params, positions, depth, cam_pos, n, f, degree, out, s);
+  if (dtype == MS_F32) launch_sh_fwd_inplace<float>(params, positions, depth, cam_pos, n, f, degree, out, s, splat_rows);
+  else launch_sh_fwd_inplace<double>(params, positions, depth, cam_pos, n, f, degree, out, s, nullptr);
   return 0;
 }
 

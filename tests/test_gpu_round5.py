@@ -163,3 +163,116 @@ def test_backward_staging_pipeline_on_every_list_length(per_tile):
     own = (a - b).abs().max(dim=1).values / b.abs().max(dim=1).values.clamp_min(1e-3 * scale)
     assert int((own > 0.5).sum()) == 0, (what, per_tile, "a splat lost most of its gradient")
     assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize('tile,heuristics,deterministic', [(16, False, False), (16, True, True), (32, False, True), (8, False, False)])
+def test_splat_row_kernels_equal_the_dense_kernels(tile, heuristics, deterministic):
+  """The product raster kernels gathering from the splat-row table (include/mi355_splat.h: ms_splat_rows_pack,
+  ms_raster_fwd_rows, ms_raster_bwd_moments_rows — what the frame executor runs) against the same kernels on the dense
+  points7 / colour arrays: identical arithmetic on identical values, so the forward image, alpha and visibility are bit
+  for bit the same, and so are the moment rows when they are committed in fixed point (float atomics add in arrival
+  order: 2e-6 of the column maximum then).  Tile 8's backward is not offered on rows (it measured slower)."""
+  import ctypes
+  from taichi_splatting_amd import _lib
+  lib = _lib.load()
+  size = (400, 304)
+  torch.manual_seed(tile)
+  g = random_2d_gaussians(30000, size, scale_factor=1.5, alpha_range=(0.1, 0.9))
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2), compute_visibility=True,
+                     compute_point_heuristic=heuristics)
+  p, depth, f = project_gaussians2d(g).to(DEV).contiguous(), g.depths.reshape(-1, 1).to(DEV), g.feature.to(DEV).contiguous()
+  o2p, ranges = map_to_tiles(p, depth, size, cfg)
+  ranges2 = ranges.view(-1, 2).contiguous()
+  n, (w, h) = p.shape[0], size
+  cfg_c, stream = _lib.raster_config_c(cfg), _lib.current_stream(torch.device(DEV))
+  th = (h + tile - 1) // tile
+  rows = torch.full((n, _lib.SPLAT_ROW), float('nan'), device=DEV)
+  _lib.check(lib.ms_splat_rows_pack(p.data_ptr(), depth.data_ptr(), f.data_ptr(), n, rows.data_ptr(), stream), "pack")
+  assert torch.equal(rows[:, :7], p) and torch.equal(rows[:, 7], depth.reshape(-1)) and torch.equal(rows[:, 8:11], f)
+
+  def forward(use_rows):
+    image, alpha, vis = torch.empty((h, w, 3), device=DEV), torch.empty((h, w), device=DEV), torch.zeros(n, device=DEV)
+    if use_rows:
+      _lib.check(lib.ms_raster_fwd_rows(rows.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, cfg_c, image.data_ptr(),
+                                        alpha.data_ptr(), vis.data_ptr(), 0, th, stream), "fwd rows")
+    else:
+      _lib.check(lib.ms_raster_fwd(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_c,
+                                   image.data_ptr(), alpha.data_ptr(), vis.data_ptr(), 0, th, _lib.dtype_code(torch.float32),
+                                   stream), "fwd")
+    return image, alpha, vis
+  (img_r, a_r, v_r), (img_d, a_d, v_d) = forward(True), forward(False)
+  assert torch.equal(img_r, img_d) and torch.equal(a_r, a_d)
+  assert (v_r - v_d).abs().max().item() <= 1e-5 * float(v_d.max())          # float atomics
+  assert float(img_d.max()) > 0.1
+
+  torch.manual_seed(1)
+  G = torch.rand_like(img_d) + 0.5
+  exps = None
+  if deterministic:
+    exps = torch.empty(2, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ms_fixed_point_exponents(G.abs().amax().reshape(1).data_ptr(), exps.data_ptr(), stream), "exp")
+
+  def backward(use_rows):
+    mom = torch.zeros((n, _lib.MOMENT_ROW), dtype=torch.int64 if deterministic else torch.float32, device=DEV)
+    args = (ranges2.data_ptr(), o2p.data_ptr(), img_d.data_ptr(), G.data_ptr(), w, h, cfg_c, mom.data_ptr(),
+            1 if deterministic else 0, exps.data_ptr() if deterministic else None, 0, th, stream)
+    if use_rows:
+      rc = lib.ms_raster_bwd_moments_rows(rows.data_ptr(), *args)
+    else:
+      rc = lib.ms_raster_bwd_moments(p.data_ptr(), f.data_ptr(), *args)
+    return rc, mom
+  rc, mom_r = backward(True)
+  if tile == 8:
+    assert rc == -2                                                     # MS_ERR_UNSUPPORTED
+    return
+  _lib.check(rc, "bwd rows")
+  rc, mom_d = backward(False)
+  _lib.check(rc, "bwd")
+  if deterministic:
+    assert torch.equal(mom_r, mom_d) and int(mom_d.abs().max()) > 0
+  else:
+    scale = mom_d.abs().amax(dim=0).clamp_min(1e-30)
+    assert float(((mom_r - mom_d).abs() / scale).max()) < 2e-6 and float(mom_d.abs().max()) > 0
+
+
+def test_frame_executor_with_splat_rows_switched_on():
+  """MS_SPLAT_ROWS=1 (read once per process, hence the subprocess): the frame executor fills the splat-row table in its
+  projection and SH kernels and rasterizes from it — SH degree 2 (the generic SH kernel writes the colour words), degree 3
+  (the streaming kernel does) and no SH (the projection kernel copies the features).  Same values gathered, same
+  arithmetic: the image is bit for bit that of a process without the table, the gradients agree to the order of their
+  float atomics."""
+  import os, subprocess, sys, textwrap
+  code = textwrap.dedent('''
+    import torch
+    from taichi_splatting_amd import RasterConfig, render_gaussians, frame
+    from taichi_splatting_amd.testing import random_3d_gaussians, random_camera
+    dev = 'cuda:0'
+    torch.manual_seed(3)
+    cam = random_camera(image_size=(320, 240))
+    out = {}
+    for name, shape, use_sh in (('deg2', (3, 9), True), ('deg3', (3, 16), True), ('rgb', (3,), False)):
+      g = random_3d_gaussians(20000, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+      g = g.replace(feature=torch.rand(20000, *shape) * (0.5 if use_sh else 1.0))
+      g, c = g.to(dev), cam.to(device=dev)
+      g.requires_grad_(True)
+      r = render_gaussians(g, c, RasterConfig(), use_sh=use_sh)
+      (r.image * torch.linspace(0.5, 1.5, 320 * 240 * 3, device=dev).view(240, 320, 3)).sum().backward()
+      out[name] = (r.image.detach().cpu(), g.position.grad.cpu(), g.feature.grad.cpu())
+    torch.save(out, OUT)
+  ''')
+  import tempfile
+  results = {}
+  with tempfile.TemporaryDirectory() as tmp:
+    for mode in ('0', '1'):
+      path = os.path.join(tmp, f'rows{mode}.pt')
+      env = dict(os.environ, MS_SPLAT_ROWS=mode)
+      subprocess.run([sys.executable, '-c', code.replace('OUT', repr(path))], check=True, env=env, timeout=300,
+                     cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+      results[mode] = torch.load(path)
+  for name in ('deg2', 'deg3', 'rgb'):
+    (img0, gp0, gf0), (img1, gp1, gf1) = results['0'][name], results['1'][name]
+    assert torch.equal(img0, img1), name
+    assert float(img0.max()) > 0.05
+    for a, b in ((gp0, gp1), (gf0, gf1)):
+      assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
+      assert float(a.abs().max()) > 0

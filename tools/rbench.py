@@ -64,6 +64,7 @@ def main():
   p.add_argument('--save', default='')
   p.add_argument('--ref', default='')
   p.add_argument('--tag', default='')
+  p.add_argument('--rows', action='store_true', help='gather from a splat-row table (ms_splat_rows_pack, ms_raster_*_rows)')
   args = p.parse_args()
 
   from taichi_splatting_amd import _lib
@@ -77,7 +78,15 @@ def main():
   image = torch.empty((h, w, 3), device=dev)
   alpha = torch.empty((h, w), device=dev)
 
+  rows = None
+  if args.rows:
+    rows = torch.zeros((n, _lib.SPLAT_ROW), device=dev)
+    _lib.check(lib.ms_splat_rows_pack(g2d.data_ptr(), None, feats.data_ptr(), n, rows.data_ptr(), stream), "pack")
+
   def fwd():
+    if rows is not None:
+      return _lib.check(lib.ms_raster_fwd_rows(rows.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, cfg_c,
+                                               image.data_ptr(), alpha.data_ptr(), None, 0, th, stream), "fwd rows")
     _lib.check(lib.ms_raster_fwd(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_c,
                                  image.data_ptr(), alpha.data_ptr(), None, 0, th, _lib.dtype_code(torch.float32), stream),
                "fwd")
@@ -87,6 +96,10 @@ def main():
   mom = torch.zeros((n, _lib.MOMENT_ROW), device=dev)
 
   def bwd():
+    if rows is not None and args.tile != 8:
+      return _lib.check(lib.ms_raster_bwd_moments_rows(rows.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), image.data_ptr(),
+                                                       grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0, th,
+                                                       stream), "bwd rows")
     _lib.check(lib.ms_raster_bwd_moments(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
                                          image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0,
                                          th, stream), "bwd")
