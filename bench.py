@@ -627,6 +627,9 @@ def main():
       if work and 'counts' in work:
         vr = valu_roofline(work, compute, stages[dom])
         result["roofline"]["compute"]["valu_roofline"] = vr
+        # (the two figures the review names, at the level it names them)
+        result["roofline"]["compute"]["algorithmic_instr"] = vr["algorithmic_instr"]
+        result["roofline"]["compute"]["algorithmic_frac"] = vr["frac"]
         if vr.get("gather_only_ms"):
           # the HBM-roofline fraction this kernel could reach if culling, blending and committing cost NOTHING: its
           # algorithmic bytes over the time the chip needs to gather the tile lists' rows (random 128-byte lines)
