@@ -260,6 +260,26 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  * the order of their float atomics (bit for bit with `deterministic`).  ms_raster_moments_finalize is unchanged (it
  * reads points7).  MS_ERR_UNSUPPORTED for configurations the product kernels do not serve (antialias, no alpha
  * blending for the forward). */
+/* Long tile runs (round 5; no counterpart in the reference, whose kernels also walk a tile's list with one thread block,
+ * rasterizer/forward.py:77-110).  A tile whose run exceeds 16 384 entries (a zoomed-out view piles the scene onto a few
+ * tiles) is cut into segments that separate workgroups blend; one pass per such tile composes the segments front to back
+ * (the forward blend is affine in (colour, transmittance)) and leaves, per segment and pixel, the state the backward
+ * starts from.  ms_raster_fwd_split = ms_raster_fwd for float32 RGB, plain pdf, alpha blending, no visibility (else
+ * MS_ERR_UNSUPPORTED), results equal to it up to the rounding of the re-associated products (1e-7 relative).
+ * `split_scratch`: ms_raster_split_scratch_bytes(k_capacity, tile_size) bytes, 256-byte aligned, k_capacity >= the number
+ * of overlaps; it carries the plan and the start states to ms_raster_bwd_moments_split (= ms_raster_bwd_moments), which
+ * must follow the forward on the same lists.  Scenes without long runs pay three near-empty launches (~10 us). */
+size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size);
+int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
+                        const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
+                        const ms_raster_config* cfg, float* out_image, float* out_alpha, void* split_scratch,
+                        int tile_row_begin, int tile_row_end, void* stream);
+int ms_raster_bwd_moments_split(const float* points7, const float* features, const int32_t* tile_ranges,
+                                const int32_t* overlap_to_point, int64_t k_capacity, const float* image,
+                                const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
+                                float* moments, int deterministic, const int32_t* fixed_exp, const void* split_scratch,
+                                int tile_row_begin, int tile_row_end, void* stream);
+
 #define MS_SPLAT_ROW 16
 int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
                        void* stream);
@@ -324,6 +344,12 @@ typedef struct ms_frame_desc {
   int32_t tile_row_begin, tile_row_end;   /* multi-GPU strip (0, INT32_MAX: whole image) */
   int32_t projected_input;
   int32_t mapper;                  /* MS_MAPPER_DIRECT / MS_MAPPER_PRESORT: the same in every call of a frame */
+  int32_t split_long_runs;         /* != 0: tile runs above 16 384 entries are cut into segments blended by separate
+                                      workgroups (ms_raster_fwd_split; float32 RGB product kernels without visibility,
+                                      ignored otherwise); the same in every call of a frame.  Costs three near-empty
+                                      launches when there is no such run: set it for scene shapes that showed one
+                                      (ms_frame_inputs.longest_run_host) */
+  int32_t reserved0;
   double near_plane, far_plane, blur_cov, clamp_margin;
   ms_raster_config raster;
 } ms_frame_desc;
@@ -341,15 +367,19 @@ typedef struct ms_frame_layout {
   /* keep_n, behind tile_ranges: the splat-row table (64 bytes per gaussian) of a process started with MS_SPLAT_ROWS=1;
    * 256 unused bytes otherwise */
   size_t splat_rows;
+  /* keep_k, behind overlap_to_point: plan and start states of the long-run segments (ms_frame_desc.split_long_runs);
+   * 256 unused bytes otherwise */
+  size_t split_scratch;
 } ms_frame_layout;
 
 typedef struct ms_frame_inputs {
   const void *position, *log_scaling, *rotation, *alpha_logit, *feature, *T_camera_world, *projection;
   const void *points7, *depth, *colours;       /* projected_input */
-  /* MS_MAPPER_DIRECT, optional (pinned host int32, device-visible): when a tile's run exceeds 16384 entries,
-   * ms_frame_map_raster writes its length there (one of them if there are several; never written otherwise).  Such a
-   * run is sorted by ONE workgroup at ~12 ns per entry — a caller that finds the word set switches the scene shape to
-   * MS_MAPPER_PRESORT, whose cost does not depend on how the overlaps are spread over the tiles
+  /* optional (pinned host int32, device-visible): when a tile's run exceeds 16384 entries, ms_frame_map_raster writes
+   * its length there (one of them if there are several; never written otherwise) — the per-tile sort of
+   * MS_MAPPER_DIRECT and the product raster forward do.  Such a run is sorted by ONE workgroup at ~12 ns per entry and
+   * rasterized by one workgroup: a caller that finds the word set switches the scene shape to MS_MAPPER_PRESORT, whose
+   * cost does not depend on how the overlaps are spread over the tiles, and sets split_long_runs
    * (taichi_splatting_amd/frame.py does). */
   int32_t* longest_run_host;
 } ms_frame_inputs;

@@ -51,7 +51,7 @@ class FrameDescC(ctypes.Structure):
     ('image_w', c_int32), ('image_h', c_int32),
     ('dtype', c_int32), ('f', c_int32), ('sh_degree', c_int32), ('depth16', c_int32),
     ('tile_row_begin', c_int32), ('tile_row_end', c_int32),
-    ('projected_input', c_int32), ('mapper', c_int32),
+    ('projected_input', c_int32), ('mapper', c_int32), ('split_long_runs', c_int32), ('reserved0', c_int32),
     ('near_plane', c_double), ('far_plane', c_double), ('blur_cov', c_double), ('clamp_margin', c_double),
     ('raster', RasterConfigC),
   ]
@@ -65,7 +65,7 @@ class FrameLayoutC(ctypes.Structure):
     'sorted_keys', 'order', 'counts', 'cum', 'ordered_points', 'tmp_n',
     'overlap_to_point',
     'keys', 'values', 'keys_sorted', 'tmp_k',
-    'splat_rows')]
+    'splat_rows', 'split_scratch')]
 
 
 class FrameInputsC(ctypes.Structure):
@@ -125,6 +125,9 @@ SIGNATURES = {
   'ms_fixed_point_exponents': (c_int, [c_void_p, c_void_p, c_void_p]),
   'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
   'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'ms_raster_split_scratch_bytes': (c_size_t, [c_int64, c_int]),
+  'ms_raster_fwd_split': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+  'ms_raster_bwd_moments_split': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
   'ms_splat_rows_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
   'ms_raster_fwd_rows': (c_int, [c_void_p] * 3 + [c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
   'ms_raster_bwd_moments_rows': (c_int, [c_void_p] * 5 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -15,6 +15,7 @@
 #include <cstring>
 #include "common.h"
 #include "frame_internal.h"
+#include "raster_common.h"
 
 namespace ms {
 
@@ -72,6 +73,12 @@ static bool frame_uses_rows(const ms_frame_desc* d) {
   return on && !d->projected_input && d->n > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype);
 }
 
+// Long tile runs cut into segments (raster_common.h): float32 RGB frames on the product kernels, no visibility sums
+static bool frame_uses_split(const ms_frame_desc* d) {
+  return d->split_long_runs != 0 && d->n > 0 && d->k_capacity > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype) &&
+         !d->raster.compute_visibility;
+}
+
 struct Carve {
   size_t off = 0;
   size_t take(size_t bytes) { const size_t o = off; off += align_up(bytes > 0 ? bytes : 1, 256); return o; }
@@ -102,6 +109,7 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->scratch_n_bytes = scratch_n.off;
 
   L->overlap_to_point = keep_k.take(k * 4);
+  L->split_scratch = keep_k.take(frame_uses_split(d) ? split_scratch_bytes(d->k_capacity, d->raster.tile_size) : 0);
   L->keep_k_bytes = keep_k.off;
 
   // 8 byte keys (tile << 32 | depth key) of the direct-order mapper; the pre-sort path (MS_MAPPER=presort) uses half
@@ -350,9 +358,12 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   const void* points7 = d.projected_input ? in->points7 : (const void*)(kn + L.points7);
   const void* colours = d.sh_degree >= 0 ? (const void*)(kn + L.colours) : (d.projected_input ? in->colours : in->feature);
   MS_CHECK_ARG(d.n == 0 || colours != nullptr, "colours are null");
+  SplitScratch split{};
+  const bool cut = frame_uses_split(desc) && keep_k != nullptr;
+  if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size);
   return raster_fwd_launch(points7, colours, frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr, ranges, o2p,
                            d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha, out_visibility, g.row_begin, g.row_end,
-                           d.dtype, stream);
+                           d.dtype, stream, cut ? &split : nullptr, in->longest_run_host);
 }
 
 extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
@@ -396,10 +407,15 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
       MS_CHECK_ARG(gr->grad_points7 != nullptr, "grad_points7 is null");
   } else if (moments) {
     MS_CHECK_ARG(gr->moments != nullptr, "moments is null");
+    // the segments of long tile runs start from the states the forward of THIS frame left in keep_k
+    SplitScratch split{};
+    const bool cut = frame_uses_split(desc) && keep_k != nullptr;
+    if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size);
     MS_TRY(raster_bwd_moments_launch(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
                                      (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end,
                                      gr->grad_image_broadcast, s,
-                                     frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr));
+                                     frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr,
+                                     cut ? &split : nullptr));
     if (raster_only)
       return moments_finalize_rezero_launch((const float*)points7, (float*)gr->moments, gr->deterministic, gr->fixed_exp,
                                             d.n, (float*)gr->grad_points7, (float*)gr->grad_colours,

@@ -122,7 +122,7 @@ bool raster_uses_splat_rows(const ms_raster_config* cfg, int f, int dtype);
 int raster_fwd_launch(const void* points7, const void* features, const float* splat_rows, const int32_t* tile_ranges,
                       const int32_t* overlap_to_point, int image_w, int image_h, int f, const ms_raster_config* cfg,
                       void* out_image, void* out_alpha, void* out_visibility, int tile_row_begin, int tile_row_end,
-                      int dtype, void* stream);
+                      int dtype, void* stream, const struct SplitScratch* split = nullptr, int32_t* long_run_word = nullptr);
 
 // ---- raster_bwd_scan.hip ----------------------------------------------------------------------------------------
 // ms_raster_bwd_moments with grad_broadcast: dL/dimage given as ONE pixel's f values (ms_frame_grads.grad_image_broadcast)
@@ -130,7 +130,7 @@ int raster_bwd_moments_launch(const void* points7, const void* features, const i
                               const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
                               int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
                               const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
-                              hipStream_t s, const float* splat_rows = nullptr);
+                              hipStream_t s, const float* splat_rows = nullptr, const struct SplitScratch* split = nullptr);
 // ms_raster_moments_finalize that also clears the rows it reads (persistent moments buffer)
 // row_stride > 0: grad_points7 / grad_features are columns of one row-major array with that many floats per row
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,

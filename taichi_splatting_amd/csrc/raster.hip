@@ -564,7 +564,8 @@ using namespace ms;
 // product-path kernels (float, F = 3, plain pdf, blending): raster_fast.hip
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
-                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows);
+                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows, const SplitScratch* split,
+                        int32_t* long_run_word);
 bool ms_raster_bwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         const void* image, const void* grad_image, int w, int h, const ms_raster_config* cfg,
                         void* gp, void* gf, void* heur, int row_begin, int num_tiles, hipStream_t s);
@@ -595,6 +596,26 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
                              void* stream) {
   return raster_fwd_launch(points7, features, nullptr, tile_ranges, overlap_to_point, image_w, image_h, f, cfg, out_image,
                            out_alpha, out_visibility, tile_row_begin, tile_row_end, dtype, stream);
+}
+
+extern "C" size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size) {
+  if (k_capacity < 0 || (tile_size != 8 && tile_size != 16 && tile_size != 32)) return 0;
+  return split_scratch_bytes(k_capacity, tile_size);
+}
+
+extern "C" int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
+                                   const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
+                                   const ms_raster_config* cfg, float* out_image, float* out_alpha, void* split_scratch,
+                                   int tile_row_begin, int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && split_scratch && k_capacity >= 0, "null pointer / negative capacity");
+  MS_CHECK_ARG((reinterpret_cast<uintptr_t>(split_scratch) & 255) == 0, "split_scratch must be 256-byte aligned");
+  if (!raster_uses_splat_rows(cfg, 3, MS_F32) || cfg->compute_visibility) {
+    set_error("ms_raster_fwd_split: float32 RGB, plain pdf, alpha blending, no visibility");
+    return MS_ERR_UNSUPPORTED;
+  }
+  const SplitScratch sc = split_scratch_carve(split_scratch, k_capacity, cfg->tile_size);
+  return raster_fwd_launch(points7, features, nullptr, tile_ranges, overlap_to_point, image_w, image_h, 3, cfg, out_image,
+                           out_alpha, nullptr, tile_row_begin, tile_row_end, MS_F32, stream, &sc, nullptr);
 }
 
 namespace ms {
@@ -647,7 +668,7 @@ bool ms::raster_uses_splat_rows(const ms_raster_config* cfg, int f, int dtype) {
 int ms::raster_fwd_launch(const void* points7, const void* features, const float* splat_rows, const int32_t* tile_ranges,
                       const int32_t* overlap_to_point, int image_w, int image_h, int f, const ms_raster_config* cfg,
                       void* out_image, void* out_alpha, void* out_visibility, int tile_row_begin, int tile_row_end,
-                      int dtype, void* stream) {
+                      int dtype, void* stream, const SplitScratch* split, int32_t* long_run_word) {
   int rc = check_raster_common(cfg, image_w, image_h, f, dtype, &tile_row_begin, &tile_row_end, "ms_raster_fwd");
   if (rc) return rc;
   MS_CHECK_ARG(tile_ranges && out_image && out_alpha, "null pointer");
@@ -658,7 +679,7 @@ int ms::raster_fwd_launch(const void* points7, const void* features, const float
   if (dtype == MS_F32 && f == 3 && !cfg->antialias && cfg->use_alpha_blending) {
     void* vis = (cfg->compute_visibility && out_visibility) ? out_visibility : nullptr;
     if (ms_raster_fwd_fast(points7, features, tile_ranges, overlap_to_point, image_w, image_h, cfg, out_image,
-                           out_alpha, vis, tile_row_begin, num_tiles, s, splat_rows)) {
+                           out_alpha, vis, tile_row_begin, num_tiles, s, splat_rows, split, long_run_word)) {
       MS_CHECK_LAUNCH();
       return 0;
     }

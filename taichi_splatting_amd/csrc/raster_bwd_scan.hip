@@ -141,7 +141,9 @@ __global__ void fixed_point_exponents_kernel(const float* __restrict__ amax, int
 // Four waves per SIMD (<= 128 VGPRs) is what the 40 KB of LDS per tile-16 workgroup allow, and the kernel is written
 // to that budget; without the bound the register allocator of ROCm 7.2 lets the tile-16 instantiation drift to 137
 // registers, i.e. three waves (tile 8 is LDS-bound at three waves per SIMD whatever it uses).
-template <int TS, bool HEUR, int SPLIT = 1, bool ROWS = false>      // ROWS: `points` = splat-row table (raster_common.h)
+// ROWS: `points` = splat-row table (common.h).  SEGS: one workgroup per SEGMENT of a long tile run; the pixel state
+// starts from what the forward's composition pass left for the segment (raster_common.h, "Long tile runs")
+template <int TS, bool HEUR, int SPLIT = 1, bool ROWS = false, bool SEGS = false>
 __global__ void __launch_bounds__(TS * TS, TS == 8 ? 1 : 4)
 raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                        const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
@@ -199,12 +201,20 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 #if MS_PRIO_MODE == 2
   __builtin_amdgcn_s_setprio(2);
 #endif
-  unsigned quarter_u;
-  // the quarter workgroups of a tile run on one XCD (they stage the same list); tiles themselves in plain order
-  const int local_tile = xcd_tile<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, blockIdx.x, SPLIT * SPLIT, &quarter_u);
-  if (local_tile < 0) return;
-  const int tile_id = rp.tile_begin + local_tile;
-  const int quarter = (int)quarter_u;
+  int tile_id, quarter = 0, seg_start = 0, seg_end = 0;
+  if constexpr (SEGS) {
+    static_assert(SPLIT == 1, "segments of whole tiles");
+    if ((int)blockIdx.x >= rp.split_counts[0]) return;
+    const int4 item = rp.split_items[blockIdx.x];
+    tile_id = item.x; seg_start = item.y; seg_end = item.z;
+  } else {
+    unsigned quarter_u;
+    // the quarter workgroups of a tile run on one XCD (they stage the same list); tiles themselves in plain order
+    const int local_tile = xcd_tile<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, blockIdx.x, SPLIT * SPLIT, &quarter_u);
+    if (local_tile < 0) return;
+    tile_id = rp.tile_begin + local_tile;
+    quarter = (int)quarter_u;
+  }
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int t = threadIdx.x, wave = t >> 6, lane = lane_id();
   const int patch_x = (tile_u * SPLIT + quarter % SPLIT) * TS + (wave % WAVES_WIDE) * 8;
@@ -221,6 +231,13 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
       G0 = grad_image[gp + 0]; G1 = grad_image[gp + 1]; G2 = grad_image[gp + 2];
       RG = image[p * 3 + 0] * G0 + image[p * 3 + 1] * G1 + image[p * 3 + 2] * G2;   // <R, G>, R = forward image
       T = 1.0f;
+      if constexpr (SEGS) {
+        // (the forward kernel's thread order inside the wave's 8 x 8 patch: row-major)
+        const int fx = (sub & 1) * 4 + (lane & 3), fy = (sub >> 1) * 4 + ((lane >> 2) & 3);
+        const float4 st = rp.split_state[(int64_t)blockIdx.x * (TS * TS) + wave * 64 + fy * 8 + fx];
+        T = st.w;                                                  // transmittance at the segment's start
+        RG -= st.x * G0 + st.y * G1 + st.z * G2;                   // <colour behind the segment's start, G>
+      }
     }
     s_pix[wave][lane] = make_float4(G0, G1, G2, T);
     s_rg[wave][lane] = RG;
@@ -234,8 +251,9 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // accumulators start at zero; the commit of a pass re-zeroes exactly what it read
   for (int i = lane; i < CAP * NACC; i += 64) (&s_acc[wave][0][0])[i] = 0.0f;
 
-  const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
+  const int start = SEGS ? seg_start : ranges[tile_id * 2 + 0], end = SEGS ? seg_end : ranges[tile_id * 2 + 1];
   if (end <= start) return;        // (uniform over the workgroup; the staging below reads the tile's list unguarded)
+  if (!SEGS && rp.split_min_run > 0 && end - start > rp.split_min_run) return;   // the segment launch has this tile
 
   // equal batches: as many as it takes to stay near BATCH_TARGET (rounded to nearest), never above BATCH
   const int total = end - start;
@@ -877,7 +895,7 @@ static int launch_scan_backward(const float* points7, const float* features,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
                                 float* moments, int deterministic, const int32_t* fixed_exp, int tile_row_begin,
                                 int tile_row_end, hipStream_t s, const char* who, int grad_broadcast = 0,
-                                const float* splat_rows = nullptr) {
+                                const float* splat_rows = nullptr, const SplitScratch* split = nullptr) {
   if (deterministic && !fixed_exp) { set_error("%s: deterministic commits need fixed_exp (ms_fixed_point_exponents)", who); return MS_ERR_BAD_ARG; }
   if (image_w <= 0 || image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
   if (!cfg->use_alpha_blending) {
@@ -892,7 +910,7 @@ static int launch_scan_backward(const float* points7, const float* features,
   if (tile_row_end > tiles_high) tile_row_end = tiles_high;
   if (tile_row_end <= tile_row_begin) return 0;
 
-  FastParams rp;
+  FastParams rp{};
   rp.width = image_w; rp.height = image_h; rp.tiles_wide = tiles_wide; rp.tile_begin = tile_row_begin * tiles_wide;
   rp.clamp_max_alpha = (float)cfg->clamp_max_alpha;
   rp.alpha_threshold = (float)cfg->alpha_threshold;
@@ -900,11 +918,24 @@ static int launch_scan_backward(const float* points7, const float* features,
   rp.deterministic = deterministic != 0;
   rp.grad_broadcast = grad_broadcast != 0;
   rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
+  if (split && ts == 32 && tile32_quarters()) split = nullptr;     // (the quarter variant walks whole tile lists)
+  if (split) {
+    rp.split_min_run = SPLIT_MIN_RUN;
+    rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
+  }
 #define MS_GO(TS, HEUR, SPLIT, ROWS) raster_bwd_scan_kernel<TS, HEUR, SPLIT, ROWS>                               \
       <<<dim3(xcd_grid<(SPLIT > 1 ? 1 : 0)>(rp.num_tiles, SPLIT * SPLIT)), dim3(TS * TS), 0, s>>>(              \
           ROWS ? splat_rows : points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp)
 #define MS_GO_TILE(TS, SPLIT, ROWS)                                                                             \
   do { if (hf) MS_GO(TS, true, SPLIT, ROWS); else MS_GO(TS, false, SPLIT, ROWS); } while (0)
+  // the segments of long tile runs (the plan and the start states are the forward's: raster_common.h); dense arrays only
+#define MS_GO_SEGS(TS)                                                                                          \
+  do {                                                                                                          \
+    if (hf) raster_bwd_scan_kernel<TS, true, 1, false, true><<<dim3((unsigned)split->item_cap), dim3(TS * TS), 0, s>>>(  \
+        points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp);          \
+    else raster_bwd_scan_kernel<TS, false, 1, false, true><<<dim3((unsigned)split->item_cap), dim3(TS * TS), 0, s>>>(    \
+        points7, features, tile_ranges, overlap_to_point, image, grad_image, rp, moments, fixed_exp);          \
+  } while (0)
   // the splat-row table serves the one-workgroup-per-tile kernels of tile 16 and 32 (tile 8 gathers inside its pass
   // loop and measured 10 % SLOWER with the 16-byte loads; the quarter-tile variant is a fallback)
   const bool hf = cfg->compute_point_heuristic;
@@ -916,16 +947,18 @@ static int launch_scan_backward(const float* points7, const float* features,
   }
 #endif
   switch (ts) {
-    case 8: MS_GO_TILE(8, 1, false); break;
-    case 16: if (splat_rows) MS_GO_TILE(16, 1, true); else MS_GO_TILE(16, 1, false); break;
+    case 8: MS_GO_TILE(8, 1, false); if (split) MS_GO_SEGS(8); break;
+    case 16: if (splat_rows) MS_GO_TILE(16, 1, true); else MS_GO_TILE(16, 1, false); if (split) MS_GO_SEGS(16); break;
     default:
       // tile 32: ONE 1024-thread workgroup per tile with 896-splat batches (152 KB LDS), or — MS_TILE32_BWD=quarters —
       // four 16 x 16 quarter workgroups per tile that each stage the whole tile list
       if (tile32_quarters()) MS_GO_TILE(16, 2, false);
       else if (splat_rows) MS_GO_TILE(32, 1, true);
       else MS_GO_TILE(32, 1, false);
+      if (split) MS_GO_SEGS(32);
       break;
   }
+#undef MS_GO_SEGS
 #undef MS_GO_TILE
 #undef MS_GO
   MS_CHECK_LAUNCH();
@@ -958,6 +991,19 @@ extern "C" int ms_raster_bwd_moments_rows(const float* rows, const int32_t* tile
   return launch_scan_backward(rows, rows, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg, moments,
                               deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
                               "ms_raster_bwd_moments_rows", 0, rows);
+}
+
+extern "C" int ms_raster_bwd_moments_split(const float* points7, const float* features, const int32_t* tile_ranges,
+                                           const int32_t* overlap_to_point, int64_t k_capacity, const float* image,
+                                           const float* grad_image, int image_w, int image_h,
+                                           const ms_raster_config* cfg, float* moments, int deterministic,
+                                           const int32_t* fixed_exp, const void* split_scratch, int tile_row_begin,
+                                           int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments && split_scratch, "null pointer");
+  const SplitScratch sc = split_scratch_carve(const_cast<void*>(split_scratch), k_capacity, cfg->tile_size);
+  return launch_scan_backward(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg,
+                              moments, deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
+                              "ms_raster_bwd_moments_split", 0, nullptr, &sc);
 }
 
 extern "C" int ms_fixed_point_exponents(const float* amax_dev, int32_t* out_exp2, void* stream) {
@@ -1010,11 +1056,11 @@ int raster_bwd_moments_launch(const void* points7, const void* features, const i
                               const int32_t* overlap_to_point, const void* image, const void* grad_image, int image_w,
                               int image_h, const ms_raster_config* cfg, float* moments, int deterministic,
                               const int32_t* fixed_exp, int tile_row_begin, int tile_row_end, int grad_broadcast,
-                              hipStream_t s, const float* splat_rows) {
+                              hipStream_t s, const float* splat_rows, const SplitScratch* split) {
   return launch_scan_backward((const float*)points7, (const float*)features, tile_ranges, overlap_to_point,
                               (const float*)image, (const float*)grad_image, image_w, image_h, cfg, moments,
                               deterministic, fixed_exp, tile_row_begin, tile_row_end, s, "ms_frame_backward", grad_broadcast,
-                              splat_rows);
+                              splat_rows, split);
 }
 
 int moments_finalize_rezero_launch(const float* points7, float* moments, int deterministic, const int32_t* fixed_exp,

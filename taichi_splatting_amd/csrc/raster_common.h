@@ -13,7 +13,53 @@ struct FastParams {
   int num_tiles;          // tiles of this launch (xcd_tile)
   int grad_broadcast;     // raster_bwd_scan.hip: dL/dimage is ONE pixel's f values, the same for every pixel (a sum /
                           // mean loss hands autograd an expanded scalar: no (H, W, f) copy is made or read)
+  // long tile runs cut into segments (below): 0 = off; > 0: the per-tile launch leaves tiles with longer runs to the
+  // per-segment launch, which reads the plan
+  int split_min_run;
+  const int4* split_items;        // (tile, first entry, last entry + 1, index of the tile's first item)
+  const int32_t* split_counts;    // [0] items, [1] long tiles, [2] plan overflow (never: the capacities are bounds)
+  float4* split_state;            // (item, pixel in the forward kernel's thread order): forward (C, P) of the segment,
+                                  // then (colour in front of the segment, transmittance at its start)
+  int32_t* long_run_word;         // pinned host word (may be NULL): the length of a run above SPLIT_MIN_RUN is noted there
 };
+
+// Long tile runs (round 5).  The raster kernels run ONE workgroup per tile; a scene that piles its splats onto a few
+// tiles (a zoomed-out view: 2.3 M overlaps on nine tiles in tools/sweep_scenes.py) then uses a few of the chip's 256
+// CUs.  The blending forward is a composition of affine maps per pixel — T' = T (1 - a), C' = C + f a T
+// (rasterizer/forward.py:99-110) — so a run may be cut anywhere: a workgroup blends segment s from (C, T) = (0, 1) and
+// leaves (C_s, P_s) per pixel; one pass per long tile composes them front to back, C = sum_s (prod_{r<s} P_r) C_s,
+// T = prod_s P_s, writes the pixel, and leaves in place of (C_s, P_s) what the BACKWARD needs to start its walk at
+// segment s: the colour in front of it and the transmittance there (backward.py:131-136 keeps exactly this running
+// state).  No gate depends on T in the forward; the backward's saturation test (T against 1 - saturate_threshold)
+// sees a T that was rounded in a different order — the same class of deviation as a pair on the blend gate.
+constexpr int SPLIT_MIN_RUN = 16384;   // runs above this are cut ...
+constexpr int SPLIT_SEG = 4096;        // ... into segments of about this many entries (a multiple of every batch size)
+constexpr int SPLIT_MAX_SEG = 64;      // at most this many per tile
+// the scratch block of one (forward, backward) pair: plan + per-(item, pixel) state, carved from caller memory
+struct SplitScratch {
+  int32_t* counts;      // 4 words
+  int4* long_tiles;     // long_cap x (tile, first item, segments, 0)
+  int4* items;          // item_cap
+  float4* state;        // item_cap x tile_size^2
+  int64_t long_cap, item_cap;
+};
+static inline int64_t split_long_capacity(int64_t k_capacity) { return k_capacity / SPLIT_MIN_RUN + 1; }
+static inline int64_t split_item_capacity(int64_t k_capacity) { return k_capacity / SPLIT_SEG + split_long_capacity(k_capacity) + 1; }
+static inline size_t split_scratch_bytes(int64_t k_capacity, int tile_size) {
+  const size_t lc = (size_t)split_long_capacity(k_capacity), ic = (size_t)split_item_capacity(k_capacity);
+  return 256 + ((lc * 16 + 255) & ~(size_t)255) + ((ic * 16 + 255) & ~(size_t)255) + ic * (size_t)tile_size * tile_size * 16;
+}
+static inline SplitScratch split_scratch_carve(void* base, int64_t k_capacity, int tile_size) {
+  SplitScratch sc;
+  char* p = (char*)base;
+  sc.long_cap = split_long_capacity(k_capacity); sc.item_cap = split_item_capacity(k_capacity);
+  sc.counts = (int32_t*)p; p += 256;
+  sc.long_tiles = (int4*)p; p += ((size_t)sc.long_cap * 16 + 255) & ~(size_t)255;
+  sc.items = (int4*)p; p += ((size_t)sc.item_cap * 16 + 255) & ~(size_t)255;
+  sc.state = (float4*)p;
+  (void)tile_size;
+  return sc;
+}
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share splats (a gaussian
 // overlaps 2.1 tiles on config D; the four quarter workgroups of a 32 x 32 tile share ALL of them), so an XCD may

@@ -36,8 +36,8 @@ constexpr float FWD_SPENT_T = 1.3552527e-20f;   // 2^-66: transmittance below wh
 constexpr unsigned FWD_XCD_CHUNK = 8;      // tiles per XCD run (xcd_tile, raster_common.h)
 constexpr unsigned BWD_XCD_CHUNK = 8;      // pixel-per-lane backward: 3.12 -> 3.08 ms at tile 32, 2.84 -> 2.79 at tile 16
 
-template <int TS, bool VIS, bool ROWS>       // ROWS: `points` is the frame's splat-row table (raster_common.h), `feats` unused
-__global__ void __launch_bounds__(TS * TS)
+template <int TS, bool VIS, bool ROWS, bool SEGS = false>   // ROWS: `points` is a splat-row table (common.h), `feats` unused;
+__global__ void __launch_bounds__(TS * TS)                  // SEGS: one workgroup per SEGMENT of a long tile run (raster_common.h)
 raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restrict__ feats,
                         const int32_t* __restrict__ ranges, const int32_t* __restrict__ o2p,
                         FastParams rp, float* __restrict__ image, float* __restrict__ image_alpha,
@@ -50,10 +50,24 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   __shared__ float s_vis[VIS ? BATCH : 1];
   __shared__ int s_spent[TS * TS / 64];
 
-  unsigned part_;
-  const int local_tile = xcd_tile<FWD_XCD_CHUNK>(rp.num_tiles, blockIdx.x, 1, &part_);
-  if (local_tile < 0) return;
-  const int tile_id = rp.tile_begin + local_tile;
+  int tile_id, start, end;
+  if constexpr (SEGS) {
+    static_assert(!VIS, "a segment does not know the transmittance in front of it: visibility takes the per-tile launch");
+    if ((int)blockIdx.x >= rp.split_counts[0]) return;
+    const int4 item = rp.split_items[blockIdx.x];
+    tile_id = item.x; start = item.y; end = item.z;
+  } else {
+    unsigned part_;
+    const int local_tile = xcd_tile<FWD_XCD_CHUNK>(rp.num_tiles, blockIdx.x, 1, &part_);
+    if (local_tile < 0) return;
+    tile_id = rp.tile_begin + local_tile;
+    start = ranges[tile_id * 2 + 0]; end = ranges[tile_id * 2 + 1];
+    if (end - start > SPLIT_MIN_RUN) {
+      // a scene shape that shows such a run is rendered with the segment launches from its next frame on (frame.py)
+      if (rp.long_run_word && threadIdx.x == 0) *rp.long_run_word = end - start;
+      if (rp.split_min_run > 0) return;                  // this frame already is: the segment launch has the tile
+    }
+  }
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int patch_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8;
@@ -68,7 +82,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   float T = in_bounds ? 1.0f : 0.0f;     // transmittance = 1 - accumulated weight
 
-  const int start = ranges[tile_id * 2 + 0], end = ranges[tile_id * 2 + 1];
   const int t = threadIdx.x;
 
   // two-deep gather pipeline: `raw` = splat data of the batch about to be staged, `next_id` = point
@@ -170,6 +183,67 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
     if (stager && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);
   }
 
+  if constexpr (SEGS) {
+    // (C_s, P_s) of this segment for the pixel; out-of-image pixels carry T = 0 throughout
+    rp.split_state[(int64_t)blockIdx.x * (TS * TS) + t] = make_float4(c0, c1, c2, T);
+    return;
+  }
+  if (in_bounds) {
+    const int64_t p = (int64_t)pix_y * rp.width + pix_x;
+    image[p * 3 + 0] = c0; image[p * 3 + 1] = c1; image[p * 3 + 2] = c2;
+    image_alpha[p] = 1.0f - T;
+  }
+}
+
+// One thread per tile of the launch: tiles whose run exceeds SPLIT_MIN_RUN are cut into <= SPLIT_MAX_SEG segments of
+// >= SPLIT_SEG entries (multiples of 256: every batch size divides them).  counts[0..2] are zero on entry.  The item
+// order depends on the order of the atomics; nothing else does (results are addressed by item).
+__global__ void __launch_bounds__(256)
+split_plan_kernel(const int32_t* __restrict__ ranges, int tile_begin, int num_tiles, int item_cap, int long_cap,
+                  int32_t* __restrict__ counts, int4* __restrict__ long_tiles, int4* __restrict__ items) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_tiles) return;
+  const int tile = tile_begin + i;
+  const int start = ranges[tile * 2 + 0], end = ranges[tile * 2 + 1], run = end - start;
+  if (run <= SPLIT_MIN_RUN) return;
+  int nseg = (run + SPLIT_SEG - 1) / SPLIT_SEG;
+  if (nseg > SPLIT_MAX_SEG) nseg = SPLIT_MAX_SEG;
+  const int seg = ((run + nseg - 1) / nseg + 255) & ~255;
+  nseg = (run + seg - 1) / seg;
+  const int first = atomicAdd(&counts[0], nseg), li = atomicAdd(&counts[1], 1);
+  if (first + nseg > item_cap || li >= long_cap) { counts[2] = 1; return; }     // (the capacities are upper bounds)
+  long_tiles[li] = make_int4(tile, first, nseg, 0);
+  for (int k = 0; k < nseg; ++k) {
+    const int b = start + k * seg, e = b + seg < end ? b + seg : end;
+    items[first + k] = make_int4(tile, b, e, first);
+  }
+}
+
+// One workgroup per long tile, thread = pixel in the forward kernel's order: front-to-back composition of the
+// segments' (C_s, P_s); each state row is replaced by (colour in front of the segment, transmittance at its start).
+template <int TS>
+__global__ void __launch_bounds__(TS * TS)
+split_combine_kernel(FastParams rp, const int4* __restrict__ long_tiles, float* __restrict__ image,
+                     float* __restrict__ image_alpha) {
+  using G = TileGeom<TS>;
+  if ((int)blockIdx.x >= rp.split_counts[1]) return;
+  const int4 lt = long_tiles[blockIdx.x];
+  const int tile_id = lt.x, first = lt.y, nseg = lt.z;
+  const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+  const int pix_x = tile_u * TS + (wave % G::WAVES_WIDE) * 8 + (lane & 7);
+  const int pix_y = tile_v * TS + (wave / G::WAVES_WIDE) * 8 + (lane >> 3);
+  const bool in_bounds = pix_x < rp.width && pix_y < rp.height;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, T = in_bounds ? 1.0f : 0.0f;
+  float4* row = rp.split_state + (int64_t)first * (TS * TS) + t;
+  float4 v = row[0];
+  for (int k = 0; k < nseg; ++k) {
+    const float4 nv = k + 1 < nseg ? row[(int64_t)(k + 1) * (TS * TS)] : v;
+    row[(int64_t)k * (TS * TS)] = make_float4(c0, c1, c2, T);
+    c0 = __builtin_fmaf(T, v.x, c0); c1 = __builtin_fmaf(T, v.y, c1); c2 = __builtin_fmaf(T, v.z, c2);
+    T *= v.w;
+    v = nv;
+  }
   if (in_bounds) {
     const int64_t p = (int64_t)pix_y * rp.width + pix_x;
     image[p * 3 + 0] = c0; image[p * 3 + 1] = c1; image[p * 3 + 2] = c2;
@@ -339,7 +413,7 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 using namespace ms;
 
 static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, int row_begin, int num_tiles) {
-  FastParams rp;
+  FastParams rp{};
   rp.width = w; rp.height = h;
   rp.tiles_wide = (w + cfg->tile_size - 1) / cfg->tile_size;
   rp.tile_begin = row_begin * rp.tiles_wide;
@@ -355,17 +429,38 @@ static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, in
 // Called from raster.hip's dispatch.  Returns true if the fast path handled the launch.
 bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ranges, const int32_t* o2p,
                         int w, int h, const ms_raster_config* cfg, void* image, void* alpha, void* visibility,
-                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows) {
-  const FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
+                        int row_begin, int num_tiles, hipStream_t s, const float* splat_rows, const SplitScratch* split,
+                        int32_t* long_run_word) {
+  FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
+  rp.long_run_word = long_run_word;
+  // long runs are cut only when a scratch block is given and no visibility is wanted (a segment does not know the
+  // transmittance in front of it)
+  const bool cut = split != nullptr && !visibility;
+  if (cut) {
+    rp.split_min_run = SPLIT_MIN_RUN;
+    rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
+    (void)hipMemsetAsync(split->counts, 0, 4 * sizeof(int32_t), s);
+    split_plan_kernel<<<dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, s>>>(
+        ranges, rp.tile_begin, num_tiles, (int)split->item_cap, (int)split->long_cap, split->counts, split->long_tiles,
+        split->items);
+  }
   const dim3 grid(xcd_grid<FWD_XCD_CHUNK>(rp.num_tiles, 1));
 #define MS_GO3(TS, VIS, ROWS)                                                                                   \
   raster_fwd_f32x3_kernel<TS, VIS, ROWS><<<grid, dim3(TS * TS), 0, s>>>(                                        \
       ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha,  \
       VIS ? (float*)visibility : nullptr)
+#define MS_SEG(TS, ROWS)                                                                                        \
+  raster_fwd_f32x3_kernel<TS, false, ROWS, true><<<dim3((unsigned)split->item_cap), dim3(TS * TS), 0, s>>>(     \
+      ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, nullptr)
 #define MS_GO(TS)                                                                                               \
   do {                                                                                                          \
     if (splat_rows) { if (visibility) MS_GO3(TS, true, true); else MS_GO3(TS, false, true); }                   \
     else { if (visibility) MS_GO3(TS, true, false); else MS_GO3(TS, false, false); }                            \
+    if (cut) {                                                                                                  \
+      if (splat_rows) MS_SEG(TS, true); else MS_SEG(TS, false);                                                 \
+      split_combine_kernel<TS><<<dim3((unsigned)split->long_cap), dim3(TS * TS), 0, s>>>(                       \
+          rp, split->long_tiles, (float*)image, (float*)alpha);                                                 \
+    }                                                                                                           \
   } while (0)
   switch (cfg->tile_size) {
     case 8: MS_GO(8); return true;
@@ -373,6 +468,7 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
     case 32: MS_GO(32); return true;
   }
 #undef MS_GO
+#undef MS_SEG
 #undef MS_GO3
   return false;
 }

@@ -62,6 +62,7 @@ _lock = threading.RLock() # guards the caches above and serialises the enqueue o
 MOMENTS_LRU = 4           # accumulator buffers kept per device (scene sizes / streams alternating in one process)
 K_SLOTS = 64              # pinned K words per device; a frame holds one from its forward until it has looked at K
 GRAPH_K_WORDS = 1024      # pinned K words per device for frames captured into HIP graphs
+SPLIT_LONG_RUNS = os.environ.get('MS_SPLIT_LONG_RUNS', '1') not in ('', '0')   # A/B switch of the long-run segments
 BROADCAST_GRAD = os.environ.get('MS_BROADCAST_GRAD', '1') not in ('', '0')   # A/B switch of grad_image_broadcast
 STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
@@ -404,6 +405,9 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
       inputs.longest_run_host = run_word[0].data_ptr()
     # the same in every call of this frame; before the first frame of a shape only the key width is known
     desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
+    # a shape that showed a run above LONG_RUN_LIMIT also has its long runs rasterized in segments (the raster forward
+    # reports such runs through the same word on either mapper sequence)
+    desc.split_long_runs = 1 if (SPLIT_LONG_RUNS and key in _presort_sticky) else 0
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")

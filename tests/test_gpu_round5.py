@@ -276,3 +276,112 @@ def test_frame_executor_with_splat_rows_switched_on():
     for a, b in ((gp0, gp1), (gf0, gf1)):
       assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), name
       assert float(a.abs().max()) > 0
+
+
+@pytest.mark.parametrize('tile,heuristics', [(16, False), (16, True), (32, False), (8, False)])
+def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuristics):
+  """120 000 + 60 000 splats piled onto two windows (runs of 20 000 - 120 000 entries on a handful of tiles, ordinary
+  tiles around them): ms_raster_fwd_split / ms_raster_bwd_moments_split cut the runs above 16 384 entries into
+  segments blended by separate workgroups (csrc/raster_common.h, "Long tile runs") and must reproduce the per-tile
+  kernels — image and alpha to float32 rounding of the re-associated transmittance products, the moment rows to 2e-5 of
+  the column maximum except for the odd splat behind a pixel whose transmittance sits on the backward's saturation
+  test.  Opacities just above the blend gate and sub-pixel footprints: no pixel saturates before the last segment, every
+  segment really blends (image_alpha ends near 0.99)."""
+  from taichi_splatting_amd import _lib
+  lib = _lib.load()
+  size = (256, 192)
+  torch.manual_seed(tile)
+  g = random_2d_gaussians(200000, size, scale_factor=1.0, alpha_range=(0.0045, 0.008))
+  n = g.position.shape[0]
+  g.position[:120000] = torch.tensor([[34.0, 34.0]]) + 12.0 * torch.rand(120000, 2)
+  g.position[120000:180000] = torch.tensor([[148.0, 100.0]]) + 8.0 * torch.rand(60000, 2)
+  g.log_scaling[:] = torch.log(0.5 + 0.5 * torch.rand(n, 2))
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2), compute_point_heuristic=heuristics)
+  p, depth, f = project_gaussians2d(g).to(DEV).contiguous(), g.depths.reshape(-1, 1).to(DEV), g.feature.to(DEV).contiguous()
+  o2p, ranges = map_to_tiles(p, depth, size, cfg)
+  ranges2 = ranges.view(-1, 2).contiguous()
+  runs = (ranges2[:, 1] - ranges2[:, 0])
+  assert int((runs > 16384).sum()) >= 2 and int(((runs > 0) & (runs <= 16384)).sum()) >= 4, runs.max()
+  k, (w, h) = o2p.shape[0], size
+  cfg_c, stream = _lib.raster_config_c(cfg), _lib.current_stream(torch.device(DEV))
+  th = (h + tile - 1) // tile
+  scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, tile),), dtype=torch.uint8, device=DEV)
+  assert scratch.data_ptr() % 256 == 0
+
+  def forward(split):
+    image, alpha = torch.full((h, w, 3), float('nan'), device=DEV), torch.full((h, w), float('nan'), device=DEV)
+    if split:
+      _lib.check(lib.ms_raster_fwd_split(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h, cfg_c,
+                                         image.data_ptr(), alpha.data_ptr(), scratch.data_ptr(), 0, th, stream), "fwd split")
+    else:
+      _lib.check(lib.ms_raster_fwd(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_c,
+                                   image.data_ptr(), alpha.data_ptr(), None, 0, th, _lib.dtype_code(torch.float32), stream), "fwd")
+    return image, alpha
+  (img_s, a_s), (img_d, a_d) = forward(True), forward(False)
+  counts = scratch[:16].view(torch.int32).cpu()
+  assert int(counts[1]) == int((runs > 16384).sum()) and int(counts[0]) >= 2 * int(counts[1]) and int(counts[2]) == 0
+  assert not bool(torch.isnan(img_s).any()) and not bool(torch.isnan(a_s).any())
+  assert (img_s - img_d).abs().max().item() < 3e-6 and (a_s - a_d).abs().max().item() < 3e-6
+  assert float(a_d.max()) > 0.5
+
+  torch.manual_seed(1)
+  G = torch.rand_like(img_d) + 0.5
+
+  def backward(split, image):
+    mom = torch.zeros((n, _lib.MOMENT_ROW), device=DEV)
+    if split:
+      _lib.check(lib.ms_raster_bwd_moments_split(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k,
+                                                 image.data_ptr(), G.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None,
+                                                 scratch.data_ptr(), 0, th, stream), "bwd split")
+    else:
+      _lib.check(lib.ms_raster_bwd_moments(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), image.data_ptr(),
+                                           G.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0, th, stream), "bwd")
+    return mom
+  mom_s, mom_d = backward(True, img_s), backward(False, img_d)
+  scale = mom_d.abs().amax(dim=0).clamp_min(1e-30)
+  rel = ((mom_s - mom_d).abs() / scale).amax(dim=1)
+  assert float(mom_d.abs().max()) > 0
+  assert int((rel > 2e-5).sum()) <= max(8, 0.002 * n), (int((rel > 2e-5).sum()), float(rel.max()))
+  assert float(rel.max()) < 0.05, float(rel.max())
+
+
+def test_frame_executor_cuts_long_runs_from_the_second_frame_on():
+  """render_gaussians on a scene whose splats pile onto a few tiles: the first frame of the shape rasterizes every tile
+  with one workgroup and notes the long run in the shape's pinned word (csrc/raster_fast.hip); from the next frame on
+  the shape maps with the pre-sort AND has its long runs blended in segments (frame.py, ms_frame_desc.split_long_runs).
+  Image and gradients of the later frames against the first: float32 rounding of re-associated products."""
+  torch.manual_seed(11)
+  size = (256, 192)
+  cam = random_camera(image_size=size)
+  n = 150000
+  g = random_3d_gaussians(n, cam, scale_factor=0.3, alpha_range=(0.005, 0.01))
+  # the generator's positions squeezed towards the view axis: everything lands on a few tiles around the image centre
+  centre = g.position.mean(dim=0, keepdim=True)
+  g = g.replace(position=centre + (g.position - centre) * torch.tensor([[0.04, 0.04, 1.0]]), feature=torch.rand(n, 3))
+  cfg = RasterConfig()
+  frame.release_caches()
+  try:
+    out = []
+    for i in range(3):
+      gd, camd = g.to(DEV), cam.to(device=DEV)
+      gd.requires_grad_(True)
+      r = render_gaussians(gd, camd, cfg, use_sh=False)
+      (r.image * torch.linspace(0.5, 1.5, size[0] * size[1] * 3, device=DEV).view(size[1], size[0], 3)).sum().backward()
+      out.append((r.image.detach().clone(), gd.position.grad.clone(), gd.feature.grad.clone(), gd.log_scaling.grad.clone()))
+      torch.cuda.synchronize()
+      key = frame._shape_key(torch.device(DEV), n, size, cfg, None, False)
+      if i == 0:
+        st = frame.frame_status(r)
+        assert st['overlaps'] > 100000
+    assert key in frame._presort_sticky, "no run above 16 384 entries: the scene does not test anything"
+    assert float(out[0][0].max()) > 0.05
+    for later in out[1:]:
+      assert (later[0] - out[0][0]).abs().max().item() < 3e-6
+      for a, b in zip(later[1:], out[0][1:]):
+        scale = float(b.abs().max())
+        assert scale > 0
+        rel = (a - b).abs().flatten(1).amax(dim=1) / scale
+        assert int((rel > 2e-5).sum()) <= max(8, 0.002 * n) and float(rel.max()) < 0.05, (int((rel > 2e-5).sum()), float(rel.max()))
+    assert torch.equal(out[1][0], out[2][0])
+  finally:
+    frame.release_caches()

@@ -7,7 +7,8 @@ whose cost per overlap exceeds GUARD x config D's.
 
   scenes   random_3d_gaussians at scale_factor 0.5 / 1 / 2 / 4 / 8  x  opacity 0.1-0.9 / 0.75-1.0  x  1024^2 / 2048^2 /
            4096^2 (the reference's three resolutions, BENCHMARK.md:36-40);  a heavy-tailed mix (5 % of the splats at
-           20 x scale);  a pile-up (every splat centred inside one 48 x 48 px window: tile runs of ~100 000 entries);
+           20 x scale);  a pile-up (every splat centred inside one 48 x 48 px window: tile runs of ~100 000 entries,
+           which the raster kernels cut into segments: ms_raster_fwd_split / ms_raster_bwd_moments_split);
            the reference's dense 2D component shape (benchmarks/bench_rasterizer.py:21-26)
 
     python tools/sweep_scenes.py [--quick] [--out profiles/r05_scene_sweep.txt]
@@ -124,12 +125,34 @@ def measure(spec, dev):
     out['raster_fwd_ms'] = cuda_ms(fwd)
     grad_image = torch.ones_like(image)
     mom = torch.zeros((v, _lib.MOMENT_ROW), device=dev)
+    # a shape with a run above 16 384 entries is rasterized in segments from its second frame on (frame.py sets
+    # ms_frame_desc.split_long_runs): those launches are what the guard judges, the per-tile launches are reported
+    long_runs = int(runs.max()) > 16384
+    out['raster'] = 'segments' if long_runs else 'per tile'
+    if long_runs:
+      scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, 16),), dtype=torch.uint8, device=dev)
+
+      def fwd_split():
+        _lib.check(lib.ms_raster_fwd_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h,
+                                           cfg_c, image.data_ptr(), alpha.data_ptr(), scratch.data_ptr(), 0, th, stream), "fwd split")
+
+      def bwd_split():
+        _lib.check(lib.ms_raster_bwd_moments_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k,
+                                                   image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None,
+                                                   scratch.data_ptr(), 0, th, stream), "bwd split")
+      out['raster_fwd_per_tile_ms'] = out['raster_fwd_ms']
+      out['raster_fwd_ms'] = cuda_ms(fwd_split)
 
     def bwd():
       _lib.check(lib.ms_raster_bwd_moments(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(),
                                            image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0,
                                            th, stream), "bwd")
     out['raster_bwd_ms'] = cuda_ms(bwd)
+    if long_runs:
+      out['raster_bwd_per_tile_ms'] = out['raster_bwd_ms']
+      fwd_split()
+      out['raster_bwd_ms'] = cuda_ms(bwd_split)
+      del scratch
     del mom, image, alpha, grad_image
   # the frame: forward + backward through the executor, and the mapper sequence it settles on
   if cam is not None:
@@ -219,7 +242,9 @@ def main():
                  f"{r['project_ms']:5.2f} {r['sh_ms']:5.2f} {r['map_auto_ms']:6.3f} {r['map_direct_ms']:6.3f} {r['map_presort_ms']:6.3f} "
                  f"{r['raster_fwd_ms']:6.3f} {r['raster_bwd_ms']:6.3f} {r.get('frame_ms', float('nan')):6.2f} {r.get('first_frame_ms', float('nan')):7.1f} | "
                  f"{r['map_ps_per_overlap']:5.1f} {r['fwd_ps_per_overlap']:5.1f} {r['bwd_ps_per_overlap']:5.1f}  "
-                 f"({rel['map']:.2f} {rel['fwd']:.2f} {rel['bwd']:.2f}) | {r.get('frame_mapper', '-'):7s} {'same' if r['lists_equal'] else 'DIFFER'}")
+                 f"({rel['map']:.2f} {rel['fwd']:.2f} {rel['bwd']:.2f}) | {r.get('frame_mapper', '-'):7s} {'same' if r['lists_equal'] else 'DIFFER'}"
+                 + (f"   long runs in segments (one workgroup per tile: fwd {r['raster_fwd_per_tile_ms']:.3f} bwd {r['raster_bwd_per_tile_ms']:.3f} ms)"
+                    if 'raster_fwd_per_tile_ms' in r else ""))
   lines.append("")
   lines.append(f"guard: cost per overlap of mapper / raster forward / raster backward <= {GUARD} x config D's")
   lines.append("flagged: " + (", ".join(f"{n}:{s} x{x}" for n, s, x in flagged) if flagged else "none"))
