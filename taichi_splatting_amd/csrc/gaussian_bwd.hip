@@ -102,7 +102,9 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
       const double s_main = ldexp(1.0, -a.fixed_exp[0]), s_h0 = ldexp(1.0, -a.fixed_exp[1]);
       float* flat = reinterpret_cast<float*>(&s_mom[wave][0]);
       wave_lds_fence();
-#pragma unroll
+      // (two rounds of four loads in flight: eight kept 32 registers busy and the kernel at 172 VGPRs = two waves per
+      // SIMD; with four it fits three like the float-row instantiation)
+#pragma unroll 4
       for (int j = 0; j < 8; ++j) {
         const int idx = j * 64 + lane, row = idx >> 3, pair = idx & 7;      // values 2 pair, 2 pair + 1 of row `row`
         if (row < count) {

@@ -2,6 +2,7 @@
 // kernel parameters, the two-deep gather pipeline's raw record, the LDS blend / cull records, the
 // conservative rectangle-vs-contribution-ellipse test and the wave64 halving butterfly.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 namespace ms {
@@ -33,8 +34,16 @@ struct FastParams {
 // state).  No gate depends on T in the forward; the backward's saturation test (T against 1 - saturate_threshold)
 // sees a T that was rounded in a different order — the same class of deviation as a pair on the blend gate.
 constexpr int SPLIT_MIN_RUN = 16384;   // runs above this are cut ...
-constexpr int SPLIT_SEG = 4096;        // ... into segments of about this many entries (a multiple of every batch size)
-constexpr int SPLIT_MAX_SEG = 64;      // at most this many per tile
+constexpr int SPLIT_MAX_SEG = 256;     // ... into at most this many segments per tile ...
+// ... of at least this many entries (a multiple of every batch size).  Short segments = many workgroups: the pile-up's
+// 2.35 M overlaps make 576 workgroups at 4096 entries (2 per CU: one wave per SIMD, latency-bound) and 2300 at 1024.
+// A tile-32 workgroup has 16 waves and 16 KB of state per segment: four times the length.  MS_SPLIT_SEG in the
+// environment (read once) overrides, for measurements.
+static inline int split_seg_len(int tile_size) {
+  static const int forced = [] { const char* e = getenv("MS_SPLIT_SEG"); const int v = e ? atoi(e) : 0; return v >= 256 ? (v + 255) & ~255 : 0; }();
+  if (forced) return forced;
+  return tile_size == 32 ? 4096 : 1024;
+}
 // the scratch block of one (forward, backward) pair: plan + per-(item, pixel) state, carved from caller memory
 struct SplitScratch {
   int32_t* counts;      // 4 words
@@ -44,20 +53,19 @@ struct SplitScratch {
   int64_t long_cap, item_cap;
 };
 static inline int64_t split_long_capacity(int64_t k_capacity) { return k_capacity / SPLIT_MIN_RUN + 1; }
-static inline int64_t split_item_capacity(int64_t k_capacity) { return k_capacity / SPLIT_SEG + split_long_capacity(k_capacity) + 1; }
+static inline int64_t split_item_capacity(int64_t k_capacity, int tile_size) { return k_capacity / split_seg_len(tile_size) + split_long_capacity(k_capacity) + 1; }
 static inline size_t split_scratch_bytes(int64_t k_capacity, int tile_size) {
-  const size_t lc = (size_t)split_long_capacity(k_capacity), ic = (size_t)split_item_capacity(k_capacity);
+  const size_t lc = (size_t)split_long_capacity(k_capacity), ic = (size_t)split_item_capacity(k_capacity, tile_size);
   return 256 + ((lc * 16 + 255) & ~(size_t)255) + ((ic * 16 + 255) & ~(size_t)255) + ic * (size_t)tile_size * tile_size * 16;
 }
 static inline SplitScratch split_scratch_carve(void* base, int64_t k_capacity, int tile_size) {
   SplitScratch sc;
   char* p = (char*)base;
-  sc.long_cap = split_long_capacity(k_capacity); sc.item_cap = split_item_capacity(k_capacity);
+  sc.long_cap = split_long_capacity(k_capacity); sc.item_cap = split_item_capacity(k_capacity, tile_size);
   sc.counts = (int32_t*)p; p += 256;
   sc.long_tiles = (int4*)p; p += ((size_t)sc.long_cap * 16 + 255) & ~(size_t)255;
   sc.items = (int4*)p; p += ((size_t)sc.item_cap * 16 + 255) & ~(size_t)255;
   sc.state = (float4*)p;
-  (void)tile_size;
   return sc;
 }
 

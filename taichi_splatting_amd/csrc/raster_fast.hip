@@ -196,17 +196,17 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 }
 
 // One thread per tile of the launch: tiles whose run exceeds SPLIT_MIN_RUN are cut into <= SPLIT_MAX_SEG segments of
-// >= SPLIT_SEG entries (multiples of 256: every batch size divides them).  counts[0..2] are zero on entry.  The item
+// >= seg_len entries (multiples of 256: every batch size divides them).  counts[0..2] are zero on entry.  The item
 // order depends on the order of the atomics; nothing else does (results are addressed by item).
 __global__ void __launch_bounds__(256)
-split_plan_kernel(const int32_t* __restrict__ ranges, int tile_begin, int num_tiles, int item_cap, int long_cap,
+split_plan_kernel(const int32_t* __restrict__ ranges, int tile_begin, int num_tiles, int seg_len, int item_cap, int long_cap,
                   int32_t* __restrict__ counts, int4* __restrict__ long_tiles, int4* __restrict__ items) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num_tiles) return;
   const int tile = tile_begin + i;
   const int start = ranges[tile * 2 + 0], end = ranges[tile * 2 + 1], run = end - start;
   if (run <= SPLIT_MIN_RUN) return;
-  int nseg = (run + SPLIT_SEG - 1) / SPLIT_SEG;
+  int nseg = (run + seg_len - 1) / seg_len;
   if (nseg > SPLIT_MAX_SEG) nseg = SPLIT_MAX_SEG;
   const int seg = ((run + nseg - 1) / nseg + 255) & ~255;
   nseg = (run + seg - 1) / seg;
@@ -441,7 +441,7 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
     rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
     (void)hipMemsetAsync(split->counts, 0, 4 * sizeof(int32_t), s);
     split_plan_kernel<<<dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, s>>>(
-        ranges, rp.tile_begin, num_tiles, (int)split->item_cap, (int)split->long_cap, split->counts, split->long_tiles,
+        ranges, rp.tile_begin, num_tiles, split_seg_len(cfg->tile_size), (int)split->item_cap, (int)split->long_cap, split->counts, split->long_tiles,
         split->items);
   }
   const dim3 grid(xcd_grid<FWD_XCD_CHUNK>(rp.num_tiles, 1));
