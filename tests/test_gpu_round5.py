@@ -383,5 +383,26 @@ def test_frame_executor_cuts_long_runs_from_the_second_frame_on():
         rel = (a - b).abs().flatten(1).amax(dim=1) / scale
         assert int((rel > 2e-5).sum()) <= max(8, 0.002 * n) and float(rel.max()) < 0.05, (int((rel > 2e-5).sum()), float(rel.max()))
     assert torch.equal(out[1][0], out[2][0])
+    # the same frame captured in a HIP graph (the plan's memset and the segment launches are part of the capture)
+    gd, camd = g.to(DEV), cam.to(device=DEV)
+    gd.requires_grad_(True)
+    leaves = [gd.position, gd.log_scaling, gd.rotation, gd.alpha_logit, gd.feature]
+    weight = torch.linspace(0.5, 1.5, size[0] * size[1] * 3, device=DEV).view(size[1], size[0], 3)
+
+    def step():
+      for t in leaves:
+        t.grad = None
+      r = render_gaussians(gd, camd, cfg, use_sh=False)
+      (r.image * weight).sum().backward()
+      return r
+    del r
+    graph = frame.FrameGraph(step, warmup=2)
+    for _ in range(2):
+      r = graph.replay()
+    torch.cuda.synchronize()
+    assert int(r.frame.desc.split_long_runs) == 1
+    assert torch.equal(r.image, out[1][0])
+    rel = (gd.position.grad - out[1][1]).abs().flatten(1).amax(dim=1) / float(out[1][1].abs().max())
+    assert float(rel.max()) < 1e-4
   finally:
     frame.release_caches()
