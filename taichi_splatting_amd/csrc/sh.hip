@@ -64,7 +64,8 @@ sh_fwd_kernel(const T* __restrict__ params, const T* __restrict__ positions,
 // adds; the quad's first lane clamps and stores (16 consecutive floats per store instruction).  Rows of culled
 // gaussians are not read.  The summation order differs from sh_fwd_kernel's (4 x 4 instead of 16 in a row): colours
 // agree to rounding, which is what both are held to against the oracle.
-__global__ void __launch_bounds__(256)
+template <bool ROWS>      // ROWS: the colours also go into the gaussians' splat rows (a template so that the default
+__global__ void __launch_bounds__(256)      // instantiation keeps its 158 VGPRs = three waves per SIMD; with the row path: 173)
 sh_fwd_rows_deg3_kernel(const float* __restrict__ params, const float* __restrict__ positions,
                         const float* __restrict__ cam_pos, const float* __restrict__ cull_depth, int64_t n,
                         float* __restrict__ out, float* __restrict__ splat_rows) {
@@ -117,13 +118,13 @@ sh_fwd_rows_deg3_kernel(const float* __restrict__ params, const float* __restric
         // splat rows: the colour goes through the four spare words of the gaussian's LDS row (k >> 2 = channel) so that
         // its lane stores ONE 16-byte piece behind the barrier below (three scattered dwords per row cost the frame more
         // than the raster kernels gain)
-        if (splat_rows) s_Y[wave][j * YS + D + (k >> 2)] = colour;
+        if constexpr (ROWS) s_Y[wave][j * YS + D + (k >> 2)] = colour;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (splat_rows && lane < count) {
+    if (ROWS && lane < count) {
       vec4 c = *reinterpret_cast<const vec4*>(&s_Y[wave][lane * YS + D]);
       c.w = 0.0f;
       *reinterpret_cast<vec4*>(splat_rows + i * SPLAT_ROW + SPLAT_ROW_COLOUR) = c;
@@ -338,9 +339,14 @@ int sh_fwd_inplace_launch(const void* params, const void* positions, const void*
   if (dtype == MS_F32 && f == 3 && degree == 3 && !rows_off && (reinterpret_cast<uintptr_t>(params) & 15) == 0) {
     int64_t blocks = div_up(n, 256);
     if (blocks > MS_SH_ROWS_BLOCKS) blocks = MS_SH_ROWS_BLOCKS;       // grid-stride: a resident grid streams best
-    sh_fwd_rows_deg3_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const float*)params, (const float*)positions,
-                                                                        (const float*)cam_pos, (const float*)depth, n,
-                                                                        (float*)out, splat_rows);
+    if (splat_rows)
+      sh_fwd_rows_deg3_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const float*)params, (const float*)positions,
+                                                                                (const float*)cam_pos, (const float*)depth, n,
+                                                                                (float*)out, splat_rows);
+    else
+      sh_fwd_rows_deg3_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const float*)params, (const float*)positions,
+                                                                                 (const float*)cam_pos, (const float*)depth, n,
+                                                                                 (float*)out, nullptr);
     return 0;
   }
   if (dtype == MS_F32) launch_sh_fwd_inplace<float>(params, positions, depth, cam_pos, n, f, degree, out, s, splat_rows);
