@@ -185,7 +185,10 @@ __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshol
     rec[0] = make_float4(mx, my, A, B);
   }
   rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -fast_log2(alpha) : alpha, r.f[0]);
-  rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
+  // (the forward reads 40 of the record's 48 bytes; it keeps its spent-wave flags in the last word of the first records,
+  // so its stagers leave words 10 and 11 alone)
+  if (FWD_FORM) *reinterpret_cast<float2*>(&rec[2]) = make_float2(r.f[1], r.f[2]);
+  else rec[2] = make_float4(r.f[1], r.f[2], isx, isy);
   // contribution ellipse  alpha * g > threshold  <=>  X^2 + Y^2 < gs^2, gs = sqrt(2 ln(alpha/thr))
   // (NaN when alpha < threshold: every comparison of the hit test fails and the splat is culled)
   const float gs = cutoff_radius(alpha, alpha_threshold) * 1.001f;

@@ -48,7 +48,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   __shared__ float4 s_cull[BATCH * 2];
   __shared__ int32_t s_id[VIS ? BATCH : 1];
   __shared__ float s_vis[VIS ? BATCH : 1];
-  __shared__ int s_spent[TS * TS / 64];
 
   int tile_id, start, end;
   if constexpr (SEGS) {
@@ -101,10 +100,14 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
     // float32 image of these features can hold, ten orders of magnitude inside the 1e-4 contract — and image_alpha =
     // 1 - T is exactly 1 either way: the workgroup stops, and a wave whose own 64 pixels are spent skips its share of
     // a batch.  (A visibility sum loses the same < 1e-17 per splat.)  One barrier: each wave posts its flag before it.
+    // The flags live in the last word of records 0 .. waves - 1, which nothing else reads or writes (write_records<true>
+    // stores 40 of a record's 48 bytes): an LDS array of their own cost the kernel its eighth workgroup per CU (20 496
+    // bytes instead of 20 480) and, with this compiler, 21 VGPRs (65 instead of 44-46) — the forward of config D ran
+    // 0.56-0.59 ms instead of 0.52-0.54 for most of round 5 (tests/test_kernel_budgets.py holds it now).
     const bool wave_spent = __ballot(T >= FWD_SPENT_T) == 0;
-    if (lane == 0) s_spent[wave] = wave_spent ? 1 : 0;
+    if (lane == 0) reinterpret_cast<int*>(&s_rec[wave * 3 + 2])[3] = wave_spent ? 1 : 0;
     __syncthreads();                       // previous batch fully consumed; flags posted
-    if (__ballot(s_spent[lane % (TS * TS / 64)] != 0) == ~0ull) break;
+    if (__ballot(reinterpret_cast<const int*>(&s_rec[(lane % (TS * TS / 64)) * 3 + 2])[3] != 0) == ~0ull) break;
     if (VIS && stager) {
       if (begin > start && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);   // previous batch
       s_vis[t] = 0.0f;
