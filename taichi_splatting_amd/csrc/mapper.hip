@@ -191,7 +191,7 @@ tile_emit_kernel(const float* __restrict__ points, const float* __restrict__ dep
 // sorted by tile with a stable radix sort and each tile's run is then depth-sorted on its own (tile_sort.hip).  The
 // result is the same (tile, depth key, point index) order as MODE 0 / MODE 2 above.
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)      // 64 VGPRs: eight waves per SIMD (the cooperative walk had taken it to 66)
 tile_count_direct_kernel(const float* __restrict__ points, const T* __restrict__ cull_depth, int64_t v, int image_w,
                          int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
                          int32_t* __restrict__ counts) {

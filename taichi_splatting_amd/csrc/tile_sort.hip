@@ -286,7 +286,7 @@ __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int
 // One workgroup per tile (runs of lo < n <= hi <= 256 * R entries; the others belong to the kernel below).  Leaves
 // alt[b] = TS_DECLINED for a run it does not sort, 0 otherwise.
 template <int R>
-__global__ void __launch_bounds__(TS_THREADS)
+__global__ void __launch_bounds__(TS_THREADS, R <= 4 ? 8 : 1)
 tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
                        uint64_t* __restrict__ alt, int lo, int hi, int32_t* __restrict__ run_stats) {
   constexpr int CAP = TS_THREADS * R;

@@ -25,12 +25,17 @@ BUDGETS = {
   'ms::gaussian_bwd_kernel<float, 3, true, false>': ('gaussian_bwd.hip', 168),
   'ms::gaussian_bwd_kernel<float, 3, true, true>': ('gaussian_bwd.hip', 168),
   'ms::project_fwd_kernel<float>': ('projection.hip', 64),
+  'ms::tile_count_direct_kernel<float>': ('mapper.hip', 64),
+  'ms::tile_emit_direct_kernel<float>': ('mapper.hip', 64),
+  'ms::tile_depth_sort_kernel<4>': ('tile_sort.hip', 64),
+  'ms::radix_downsweep_kernel<unsigned long, ms::PlainPairs<unsigned long> >': ('scan_sort.hip', 168),
 }
 
 
 LDS_BUDGETS = {
   'ms::raster_fwd_f32x3_kernel<16, false, false, false>': 20480,     # 8 x 20 480 = the CU's 160 KB
   'ms::raster_bwd_scan_kernel<16, false, 1, false, false>': 40960,   # 4 workgroups per CU
+  'ms::radix_downsweep_kernel<unsigned long, ms::PlainPairs<unsigned long> >': 54608,   # 3 workgroups per CU
 }
 
 
