@@ -264,16 +264,16 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  * rasterizer/forward.py:77-110).  A tile whose run exceeds 16 384 entries (a zoomed-out view piles the scene onto a few
  * tiles) is cut into segments that separate workgroups blend; one pass per such tile composes the segments front to back
  * (the forward blend is affine in (colour, transmittance)) and leaves, per segment and pixel, the state the backward
- * starts from.  ms_raster_fwd_split = ms_raster_fwd for float32 RGB, plain pdf, alpha blending, no visibility (else
- * MS_ERR_UNSUPPORTED), results equal to it up to the rounding of the re-associated products (1e-7 relative).
+ * starts from.  ms_raster_fwd_split = ms_raster_fwd for float32 RGB, plain pdf, alpha blending (else MS_ERR_UNSUPPORTED;
+ * with cfg->compute_visibility and out_visibility the segments are walked a second time, from their true start), results equal to it up to the rounding of the re-associated products (1e-7 relative).
  * `split_scratch`: ms_raster_split_scratch_bytes(k_capacity, tile_size) bytes, 256-byte aligned, k_capacity >= the number
  * of overlaps; it carries the plan and the start states to ms_raster_bwd_moments_split (= ms_raster_bwd_moments), which
  * must follow the forward on the same lists.  Scenes without long runs pay three near-empty launches (~10 us). */
 size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size);
 int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
                         const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
-                        const ms_raster_config* cfg, float* out_image, float* out_alpha, void* split_scratch,
-                        int tile_row_begin, int tile_row_end, void* stream);
+                        const ms_raster_config* cfg, float* out_image, float* out_alpha, float* out_visibility,
+                        void* split_scratch, int tile_row_begin, int tile_row_end, void* stream);
 int ms_raster_bwd_moments_split(const float* points7, const float* features, const int32_t* tile_ranges,
                                 const int32_t* overlap_to_point, int64_t k_capacity, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
@@ -345,8 +345,8 @@ typedef struct ms_frame_desc {
   int32_t projected_input;
   int32_t mapper;                  /* MS_MAPPER_DIRECT / MS_MAPPER_PRESORT: the same in every call of a frame */
   int32_t split_long_runs;         /* != 0: tile runs above 16 384 entries are cut into segments blended by separate
-                                      workgroups (ms_raster_fwd_split; float32 RGB product kernels without visibility,
-                                      ignored otherwise); the same in every call of a frame.  Costs three near-empty
+                                      workgroups (ms_raster_fwd_split; float32 RGB product kernels, ignored
+                                      otherwise); the same in every call of a frame.  Costs three near-empty
                                       launches when there is no such run: set it for scene shapes that showed one
                                       (ms_frame_inputs.longest_run_host) */
   int32_t reserved0;

@@ -126,7 +126,7 @@ SIGNATURES = {
   'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
   'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_raster_split_scratch_bytes': (c_size_t, [c_int64, c_int]),
-  'ms_raster_fwd_split': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+  'ms_raster_fwd_split': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
   'ms_raster_bwd_moments_split': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
   'ms_splat_rows_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
   'ms_raster_fwd_rows': (c_int, [c_void_p] * 3 + [c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),

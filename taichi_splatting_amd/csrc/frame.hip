@@ -73,10 +73,9 @@ static bool frame_uses_rows(const ms_frame_desc* d) {
   return on && !d->projected_input && d->n > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype);
 }
 
-// Long tile runs cut into segments (raster_common.h): float32 RGB frames on the product kernels, no visibility sums
+// Long tile runs cut into segments (raster_common.h): float32 RGB frames on the product kernels
 static bool frame_uses_split(const ms_frame_desc* d) {
-  return d->split_long_runs != 0 && d->n > 0 && d->k_capacity > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype) &&
-         !d->raster.compute_visibility;
+  return d->split_long_runs != 0 && d->n > 0 && d->k_capacity > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype);
 }
 
 struct Carve {

@@ -605,17 +605,18 @@ extern "C" size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_siz
 
 extern "C" int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
                                    const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
-                                   const ms_raster_config* cfg, float* out_image, float* out_alpha, void* split_scratch,
-                                   int tile_row_begin, int tile_row_end, void* stream) {
+                                   const ms_raster_config* cfg, float* out_image, float* out_alpha,
+                                   float* out_visibility, void* split_scratch, int tile_row_begin, int tile_row_end,
+                                   void* stream) {
   MS_CHECK_ARG(cfg && split_scratch && k_capacity >= 0, "null pointer / negative capacity");
   MS_CHECK_ARG((reinterpret_cast<uintptr_t>(split_scratch) & 255) == 0, "split_scratch must be 256-byte aligned");
-  if (!raster_uses_splat_rows(cfg, 3, MS_F32) || cfg->compute_visibility) {
-    set_error("ms_raster_fwd_split: float32 RGB, plain pdf, alpha blending, no visibility");
+  if (!raster_uses_splat_rows(cfg, 3, MS_F32)) {
+    set_error("ms_raster_fwd_split: float32 RGB, plain pdf, alpha blending");
     return MS_ERR_UNSUPPORTED;
   }
   const SplitScratch sc = split_scratch_carve(split_scratch, k_capacity, cfg->tile_size);
   return raster_fwd_launch(points7, features, nullptr, tile_ranges, overlap_to_point, image_w, image_h, 3, cfg, out_image,
-                           out_alpha, nullptr, tile_row_begin, tile_row_end, MS_F32, stream, &sc, nullptr);
+                           out_alpha, out_visibility, tile_row_begin, tile_row_end, MS_F32, stream, &sc, nullptr);
 }
 
 namespace ms {

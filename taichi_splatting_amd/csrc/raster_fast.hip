@@ -51,7 +51,6 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 
   int tile_id, start, end;
   if constexpr (SEGS) {
-    static_assert(!VIS, "a segment does not know the transmittance in front of it: visibility takes the per-tile launch");
     if ((int)blockIdx.x >= rp.split_counts[0]) return;
     const int4 item = rp.split_items[blockIdx.x];
     tile_id = item.x; start = item.y; end = item.z;
@@ -80,6 +79,9 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
   float T = in_bounds ? 1.0f : 0.0f;     // transmittance = 1 - accumulated weight
+  // SEGS + VIS = the SECOND walk of a segment, behind the composition pass: it starts from the true transmittance at
+  // the segment's start (what the composition left in the state) and exists for the visibility sums only
+  if constexpr (SEGS && VIS) T = rp.split_state[(int64_t)blockIdx.x * (TS * TS) + threadIdx.x].w;
 
   const int t = threadIdx.x;
 
@@ -188,7 +190,7 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 
   if constexpr (SEGS) {
     // (C_s, P_s) of this segment for the pixel; out-of-image pixels carry T = 0 throughout
-    rp.split_state[(int64_t)blockIdx.x * (TS * TS) + t] = make_float4(c0, c1, c2, T);
+    if constexpr (!VIS) rp.split_state[(int64_t)blockIdx.x * (TS * TS) + t] = make_float4(c0, c1, c2, T);
     return;
   }
   if (in_bounds) {
@@ -436,9 +438,9 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
                         int32_t* long_run_word) {
   FastParams rp = make_fast_params(w, h, cfg, row_begin, num_tiles);
   rp.long_run_word = long_run_word;
-  // long runs are cut only when a scratch block is given and no visibility is wanted (a segment does not know the
-  // transmittance in front of it)
-  const bool cut = split != nullptr && !visibility;
+  // long runs are cut when a scratch block is given; with visibility every segment is walked twice (a segment does not
+  // know the transmittance in front of it before the composition pass has run)
+  const bool cut = split != nullptr;
   if (cut) {
     rp.split_min_run = SPLIT_MIN_RUN;
     rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
@@ -452,17 +454,19 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
   raster_fwd_f32x3_kernel<TS, VIS, ROWS><<<grid, dim3(TS * TS), 0, s>>>(                                        \
       ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha,  \
       VIS ? (float*)visibility : nullptr)
-#define MS_SEG(TS, ROWS)                                                                                        \
-  raster_fwd_f32x3_kernel<TS, false, ROWS, true><<<dim3((unsigned)split->item_cap), dim3(TS * TS), 0, s>>>(     \
-      ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, nullptr)
+#define MS_SEG(TS, VIS, ROWS)                                                                                   \
+  raster_fwd_f32x3_kernel<TS, VIS, ROWS, true><<<dim3((unsigned)split->item_cap), dim3(TS * TS), 0, s>>>(       \
+      ROWS ? splat_rows : (const float*)points, (const float*)feats, ranges, o2p, rp, (float*)image, (float*)alpha, \
+      VIS ? (float*)visibility : nullptr)
 #define MS_GO(TS)                                                                                               \
   do {                                                                                                          \
     if (splat_rows) { if (visibility) MS_GO3(TS, true, true); else MS_GO3(TS, false, true); }                   \
     else { if (visibility) MS_GO3(TS, true, false); else MS_GO3(TS, false, false); }                            \
     if (cut) {                                                                                                  \
-      if (splat_rows) MS_SEG(TS, true); else MS_SEG(TS, false);                                                 \
+      if (splat_rows) MS_SEG(TS, false, true); else MS_SEG(TS, false, false);                                   \
       split_combine_kernel<TS><<<dim3((unsigned)split->long_cap), dim3(TS * TS), 0, s>>>(                       \
           rp, split->long_tiles, (float*)image, (float*)alpha);                                                 \
+      if (visibility) { if (splat_rows) MS_SEG(TS, true, true); else MS_SEG(TS, true, false); }                 \
     }                                                                                                           \
   } while (0)
   switch (cfg->tile_size) {

@@ -278,8 +278,8 @@ def test_frame_executor_with_splat_rows_switched_on():
       assert float(a.abs().max()) > 0
 
 
-@pytest.mark.parametrize('tile,heuristics', [(16, False), (16, True), (32, False), (8, False)])
-def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuristics):
+@pytest.mark.parametrize('tile,heuristics,visibility', [(16, False, True), (16, True, False), (32, False, True), (8, False, False)])
+def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuristics, visibility):
   """120 000 + 60 000 splats piled onto two windows (runs of 20 000 - 120 000 entries on a handful of tiles, ordinary
   tiles around them): ms_raster_fwd_split / ms_raster_bwd_moments_split cut the runs above 16 384 entries into
   segments blended by separate workgroups (csrc/raster_common.h, "Long tile runs") and must reproduce the per-tile
@@ -296,7 +296,8 @@ def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuri
   g.position[:120000] = torch.tensor([[34.0, 34.0]]) + 12.0 * torch.rand(120000, 2)
   g.position[120000:180000] = torch.tensor([[148.0, 100.0]]) + 8.0 * torch.rand(60000, 2)
   g.log_scaling[:] = torch.log(0.5 + 0.5 * torch.rand(n, 2))
-  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2), compute_point_heuristic=heuristics)
+  cfg = RasterConfig(tile_size=tile, pixel_stride=(1, 1) if tile == 8 else (2, 2), compute_point_heuristic=heuristics,
+                     compute_visibility=visibility)
   p, depth, f = project_gaussians2d(g).to(DEV).contiguous(), g.depths.reshape(-1, 1).to(DEV), g.feature.to(DEV).contiguous()
   o2p, ranges = map_to_tiles(p, depth, size, cfg)
   ranges2 = ranges.view(-1, 2).contiguous()
@@ -310,14 +311,20 @@ def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuri
 
   def forward(split):
     image, alpha = torch.full((h, w, 3), float('nan'), device=DEV), torch.full((h, w), float('nan'), device=DEV)
+    vis = torch.zeros(n, device=DEV) if visibility else None
     if split:
       _lib.check(lib.ms_raster_fwd_split(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h, cfg_c,
-                                         image.data_ptr(), alpha.data_ptr(), scratch.data_ptr(), 0, th, stream), "fwd split")
+                                         image.data_ptr(), alpha.data_ptr(), _lib.ptr(vis), scratch.data_ptr(), 0, th, stream),
+                 "fwd split")
     else:
       _lib.check(lib.ms_raster_fwd(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_c,
-                                   image.data_ptr(), alpha.data_ptr(), None, 0, th, _lib.dtype_code(torch.float32), stream), "fwd")
-    return image, alpha
-  (img_s, a_s), (img_d, a_d) = forward(True), forward(False)
+                                   image.data_ptr(), alpha.data_ptr(), _lib.ptr(vis), 0, th, _lib.dtype_code(torch.float32),
+                                   stream), "fwd")
+    return image, alpha, vis
+  (img_s, a_s, vis_s), (img_d, a_d, vis_d) = forward(True), forward(False)
+  if visibility:
+    # per-splat sums of the blend weights: the segments are walked a second time from their true transmittance
+    assert float(vis_d.max()) > 0 and (vis_s - vis_d).abs().max().item() <= 2e-5 * float(vis_d.max())
   counts = scratch[:16].view(torch.int32).cpu()
   assert int(counts[1]) == int((runs > 16384).sum()) and int(counts[0]) >= 2 * int(counts[1]) and int(counts[2]) == 0
   assert not bool(torch.isnan(img_s).any()) and not bool(torch.isnan(a_s).any())

@@ -134,7 +134,7 @@ def measure(spec, dev):
 
       def fwd_split():
         _lib.check(lib.ms_raster_fwd_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h,
-                                           cfg_c, image.data_ptr(), alpha.data_ptr(), scratch.data_ptr(), 0, th, stream), "fwd split")
+                                           cfg_c, image.data_ptr(), alpha.data_ptr(), None, scratch.data_ptr(), 0, th, stream), "fwd split")
 
       def bwd_split():
         _lib.check(lib.ms_raster_bwd_moments_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k,
