@@ -54,9 +54,10 @@ def parse_args():
   p.add_argument('--tile', type=int, default=16)
   p.add_argument('--sh-degree', type=int, default=3)
   p.add_argument('--seed', type=int, default=0)
-  p.add_argument('--spin-up', type=int, default=100,
+  p.add_argument('--spin-up', type=int, default=800,
                  help='untimed frames before the warm-up steps (GPU clock ramp: a GPU that idled while the scene was built '
-                      'runs its first seconds below its sustained clocks); single GPU: 2.5 s of frames; 0 = off')
+                      'runs its first seconds below its sustained clocks); single GPU: 2.5 s of frames; N ranks: this many rank steps '
+                      '(a fixed count, every rank runs the same collectives: 800 steps of 1-2.5 ms = 1-2 s); 0 = off')
   p.add_argument('--no-cpu-baseline', action='store_true')
   p.add_argument('--no-stages', action='store_true')
   p.add_argument('--mode', choices=['auto', 'single', 'sharded', 'strips', 'both'], default='auto',
@@ -405,7 +406,8 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
     while time.perf_counter() - t_spin < SPIN_UP_SECONDS:
       step()
   else:
-    for _ in range(args.spin_up):
+    # (a dry run checks the collectives, not the clocks: its steps go through the host)
+    for _ in range(min(args.spin_up, 20) if args.dry_run else args.spin_up):
       step()
   torch.cuda.synchronize()
   for i in range(args.warmup):
