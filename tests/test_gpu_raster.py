@@ -284,9 +284,9 @@ def test_empty_inputs_and_requires_grad_subsets():
   assert fg.grad is not None and fg.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize('tile_size', [8, 16, 32])
-@pytest.mark.parametrize('n,size,scale,alpha', [(20000, (333, 200), 1.0, (0.1, 0.9)), (8000, (96, 64), 6.0, (0.6, 1.0)),
-                                                 (70000, (640, 480), 1.0, (0.1, 0.9))])
+@pytest.mark.parametrize('tile_size,n,size,scale,alpha',
+                         [(t, *case) for t in (8, 16, 32) for case in ((20000, (333, 200), 1.0, (0.1, 0.9)), (8000, (96, 64), 6.0, (0.6, 1.0)))]
+                         + [(16, 70000, (640, 480), 1.0, (0.1, 0.9))])      # the large case at the product tile size only (suite time)
 def test_f32_product_kernels_match_f64_generic_kernels(tile_size, n, size, scale, alpha):
   # the hand-tuned float/RGB kernels (raster_fast.hip forward, raster_bwd_scan.hip backward) against the generic
   # f64 instantiation (itself checked against the oracle above), incl. many LDS batches per tile, image sizes

@@ -7,5 +7,5 @@ python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "
 python bench.py > $out/bench.log 2>&1
 tail -1 $out/bench.log | cut -c1-400
 bash tools/round_numbers.sh > $out/round_numbers.txt 2>&1
-( time timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 ) > $out/pytest_full.txt 2>&1
+( time timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=25 ) > $out/pytest_full.txt 2>&1
 tail -22 $out/pytest_full.txt
