@@ -26,14 +26,22 @@
 extern "C" {
 #endif
 
-#define MS_VERSION 400  /* 0.4.0: ms_frame_desc.mapper, ms_tile_depth_sort, ms_tile_emit_keys64; ms_frame_grads.boundary_form / grad_image_broadcast */
+/* 0.5.0 (round 6).  The hundreds digit is the ABI generation: it changes whenever a struct below changes layout or a
+ * function changes its signature.  500: ms_frame_desc / ms_frame_inputs / ms_frame_grads start with their own size (and
+ * ms_frame_desc with the caller's MS_VERSION) — every ms_frame_* call rejects a struct of another size or generation
+ * with MS_ERR_ABI instead of reading fields that are not where it expects them (round 5 grew ms_frame_desc and
+ * ms_frame_layout under version 400); split_min_run / split_seg_len parameters of the ms_raster_*_split functions,
+ * ms_frame_desc.split_seg_len; ms_optim_* (fused optimiser groups). */
+#define MS_VERSION 500
+#define MS_ABI_GENERATION(version) ((version) / 100)
 
 enum { MS_F32 = 0, MS_F64 = 1 };
 
 enum {
   MS_ERR_BAD_ARG = -1,      /* null pointer / negative size / unsupported enum */
   MS_ERR_UNSUPPORTED = -2,  /* valid request with no compiled instantiation (e.g. F > 4) */
-  MS_ERR_TMP_TOO_SMALL = -3
+  MS_ERR_TMP_TOO_SMALL = -3,
+  MS_ERR_ABI = -4           /* a struct's leading struct_size / abi_version is not this library's */
 };
 
 /* Compile-time constants of the reference's RasterConfig (data_types.py:17-47) that the raster
@@ -269,16 +277,23 @@ int ms_raster_moments_finalize(const void* points7, const float* moments, int de
  * `split_scratch`: ms_raster_split_scratch_bytes(k_capacity, tile_size) bytes, 256-byte aligned, k_capacity >= the number
  * of overlaps; it carries the plan and the start states to ms_raster_bwd_moments_split (= ms_raster_bwd_moments), which
  * must follow the forward on the same lists.  Scenes without long runs pay three near-empty launches (~10 us). */
-size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size);
+/* split_min_run / split_seg_len (round 6): a run is cut when it has MORE than split_min_run entries, into segments of at
+ * least split_seg_len entries (rounded up to a multiple of 256, at most 256 segments per tile).  0 = the defaults (16 384;
+ * 1024 entries, 4096 at tile 32); values below 256 are raised to 256.  The three calls of a (scratch, forward, backward)
+ * group must be given the same pair.  If k_capacity is below the real overlap count the plan may not fit its capacities:
+ * it is then dropped as a whole (scratch word [2] = 1) and every tile is rendered by its own workgroup — slower, same
+ * results. */
+size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size, int split_min_run, int split_seg_len);
 int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
                         const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
                         const ms_raster_config* cfg, float* out_image, float* out_alpha, float* out_visibility,
-                        void* split_scratch, int tile_row_begin, int tile_row_end, void* stream);
+                        void* split_scratch, int split_min_run, int split_seg_len, int tile_row_begin, int tile_row_end,
+                        void* stream);
 int ms_raster_bwd_moments_split(const float* points7, const float* features, const int32_t* tile_ranges,
                                 const int32_t* overlap_to_point, int64_t k_capacity, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
                                 float* moments, int deterministic, const int32_t* fixed_exp, const void* split_scratch,
-                                int tile_row_begin, int tile_row_end, void* stream);
+                                int split_min_run, int split_seg_len, int tile_row_begin, int tile_row_end, void* stream);
 
 #define MS_SPLAT_ROW 16
 int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
@@ -334,6 +349,8 @@ int ms_raster_bwd_moments_rows(const float* rows, const int32_t* tile_ranges, co
 #define MS_MAPPER_PRESORT 1
 
 typedef struct ms_frame_desc {
+  uint32_t struct_size;            /* sizeof(ms_frame_desc) of the header the caller was compiled against ... */
+  uint32_t abi_version;            /* ... and its MS_VERSION: another size or ABI generation is refused (MS_ERR_ABI) */
   int64_t n;                       /* gaussians = rows of every per-gaussian array */
   int64_t k_capacity;              /* rows of the overlap list */
   int32_t image_w, image_h;
@@ -344,12 +361,13 @@ typedef struct ms_frame_desc {
   int32_t tile_row_begin, tile_row_end;   /* multi-GPU strip (0, INT32_MAX: whole image) */
   int32_t projected_input;
   int32_t mapper;                  /* MS_MAPPER_DIRECT / MS_MAPPER_PRESORT: the same in every call of a frame */
-  int32_t split_long_runs;         /* != 0: tile runs above 16 384 entries are cut into segments blended by separate
-                                      workgroups (ms_raster_fwd_split; float32 RGB product kernels, ignored
-                                      otherwise); the same in every call of a frame.  Costs three near-empty
+  int32_t split_long_runs;         /* != 0: long tile runs are cut into segments blended by separate workgroups
+                                      (ms_raster_fwd_split; float32 RGB product kernels, ignored otherwise); the same
+                                      in every call of a frame.  1: runs above 16 384 entries; > 1: runs above that
+                                      many entries (ms_raster_fwd_split's split_min_run).  Costs three near-empty
                                       launches when there is no such run: set it for scene shapes that showed one
                                       (ms_frame_inputs.longest_run_host) */
-  int32_t reserved0;
+  int32_t split_seg_len;           /* 0: the default segment length; else ms_raster_fwd_split's split_seg_len */
   double near_plane, far_plane, blur_cov, clamp_margin;
   ms_raster_config raster;
 } ms_frame_desc;
@@ -373,6 +391,8 @@ typedef struct ms_frame_layout {
 } ms_frame_layout;
 
 typedef struct ms_frame_inputs {
+  uint32_t struct_size;            /* sizeof(ms_frame_inputs) */
+  uint32_t reserved;
   const void *position, *log_scaling, *rotation, *alpha_logit, *feature, *T_camera_world, *projection;
   const void *points7, *depth, *colours;       /* projected_input */
   /* optional (pinned host int32, device-visible): when a tile's run exceeds 16384 entries, ms_frame_map_raster writes
@@ -387,6 +407,8 @@ typedef struct ms_frame_inputs {
 enum { MS_BACKWARD_ALL = 0, MS_BACKWARD_GAUSSIANS = 1, MS_BACKWARD_RASTER = 2 };
 
 typedef struct ms_frame_grads {
+  uint32_t struct_size;            /* sizeof(ms_frame_grads) */
+  uint32_t reserved;
   const void* image;               /* forward image (H, W, f) */
   const void* grad_image;
   const void *extra_points7, *extra_depth, *extra_colours;   /* dL/d(frame's own per-gaussian outputs), may be NULL */

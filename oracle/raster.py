@@ -276,6 +276,51 @@ def near_gate(points, ranges, o2p, image_size, cfg, eps: float, return_counts: b
   return pixel_flag, splat_flag
 
 
+def saturation_margin(points, ranges, o2p, image_size, cfg):
+  """Where the BACKWARD's saturation test can legitimately flip in float32.  backward.py:154,160 drop a (pixel, splat)
+  pair once the accumulated weight in front of it reaches ``saturate_threshold``, i.e. once the transmittance T in front
+  falls to ``1 - saturate_threshold``; a float32 T (a product of up to thousands of factors, re-associated when a tile's
+  list is cut into segments) is within ~1e-5 relative of the float64 one.  Returns, per splat,
+
+    margin (V,): min over its gated (pixel, splat) pairs of |T_before / (1 - saturate_threshold) - 1|   (inf: no pair)
+    side (V,) int8: at that nearest pair, +1 = still blending (T above the limit), -1 = dropped, 0 = no pair
+
+  A pair that flips toggles a contribution of weight <= alpha (1 - saturate_threshold): tests use the margin to say
+  WHICH rows may carry such a toggle instead of allowing a count of deviating rows."""
+  w, h = image_size
+  ts = cfg.tile_size
+  tiles_wide, tiles_high = _tiles(image_size, ts)
+  dtype = points.dtype
+  V = points.shape[0]
+  margin = torch.full((V,), float('inf'), dtype=dtype)
+  side = torch.zeros((V,), dtype=torch.int8)
+  limit = 1.0 - cfg.saturate_threshold
+  ranges = ranges.reshape(-1, 2)
+  for tile_id in range(tiles_wide * tiles_high):
+    start, end = int(ranges[tile_id, 0]), int(ranges[tile_id, 1])
+    if end <= start:
+      continue
+    px, py, inb, pix = _tile_pixels(tile_id, tiles_wide, ts, w, h, dtype)
+    if not bool(inb.any()):
+      continue
+    ids = o2p[start:end].long()
+    g = points[ids]
+    a_raw = g[None, :, 6] * pdf(pix[inb], g, cfg.antialias)
+    gate = a_raw > cfg.alpha_threshold
+    a = torch.where(gate, torch.clamp_max(a_raw, cfg.clamp_max_alpha), torch.zeros_like(a_raw))
+    T_incl = torch.cumprod(1 - a, dim=1)
+    T_excl = torch.cat([torch.ones((a.shape[0], 1), dtype=dtype), T_incl[:, :-1]], dim=1)
+    rel = T_excl / limit - 1
+    dist = torch.where(gate, rel.abs(), torch.full_like(rel, float('inf')))
+    m, arg = dist.min(dim=0)
+    s = torch.sign(rel.gather(0, arg[None])[0]).to(torch.int8)
+    s = torch.where(torch.isinf(m), torch.zeros_like(s), s)
+    better = m < margin[ids]
+    margin[ids[better]] = m[better]
+    side[ids[better]] = s[better]
+  return margin, side
+
+
 def backward(points, feats, ranges, o2p, image, grad_image, image_size, cfg,
              tile_rows: Optional[Tuple[int, int]] = None):
   """Literal restatement of backward.py:97-224.  Returns grad_points (V,7), grad_feats (V,F),

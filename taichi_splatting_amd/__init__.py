@@ -18,7 +18,7 @@ from . import optim
 from .perspective import CameraParams
 from .taichi_queue import TaichiQueue, taichi_queue, queued
 
-__version__ = '0.4.0'       # = MS_VERSION 400 of include/mi355_splat.h (tests/test_abi.py holds the two together)
+__version__ = '0.5.0'       # = MS_VERSION 500 of include/mi355_splat.h (tests/test_abi.py holds the two together)
 
 __all__ = [
   'render_gaussians', 'Rendering',

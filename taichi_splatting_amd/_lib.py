@@ -23,6 +23,7 @@ MS_F32, MS_F64 = 0, 1
 BACKWARD_ALL, BACKWARD_GAUSSIANS, BACKWARD_RASTER = 0, 1, 2   # ms_frame_grads.stage
 BOUNDARY_AXIS_SIGMA, BOUNDARY_COVARIANCE = 0, 1
 MAPPER_DIRECT, MAPPER_PRESORT = 0, 1               # ms_frame_grads.boundary_form
+ABI_VERSION = 500  # MS_VERSION of include/mi355_splat.h this binding was written against (tests/test_abi.py)
 MOMENT_ROW = 16   # MS_MOMENT_ROW of include/mi355_splat.h
 SPLAT_ROW = 16    # MS_SPLAT_ROW
 
@@ -44,14 +45,27 @@ class RasterConfigC(ctypes.Structure):
   ]
 
 
-class FrameDescC(ctypes.Structure):
+class _SizedStructure(ctypes.Structure):
+  """C-ABI structs that begin with their own size (include/mi355_splat.h, MS_VERSION 500): filled in on construction,
+  checked by the library on every ms_frame_* call."""
+
+  def __init__(self, *args, **kw):
+    assert not args, "keyword arguments only: the leading fields are the struct's size / ABI version"
+    super().__init__(**kw)
+    self.struct_size = ctypes.sizeof(type(self))
+    if hasattr(self, 'abi_version'):
+      self.abi_version = ABI_VERSION
+
+
+class FrameDescC(_SizedStructure):
   """``ms_frame_desc`` of include/mi355_splat.h"""
   _fields_ = [
+    ('struct_size', ctypes.c_uint32), ('abi_version', ctypes.c_uint32),
     ('n', c_int64), ('k_capacity', c_int64),
     ('image_w', c_int32), ('image_h', c_int32),
     ('dtype', c_int32), ('f', c_int32), ('sh_degree', c_int32), ('depth16', c_int32),
     ('tile_row_begin', c_int32), ('tile_row_end', c_int32),
-    ('projected_input', c_int32), ('mapper', c_int32), ('split_long_runs', c_int32), ('reserved0', c_int32),
+    ('projected_input', c_int32), ('mapper', c_int32), ('split_long_runs', c_int32), ('split_seg_len', c_int32),
     ('near_plane', c_double), ('far_plane', c_double), ('blur_cov', c_double), ('clamp_margin', c_double),
     ('raster', RasterConfigC),
   ]
@@ -68,16 +82,17 @@ class FrameLayoutC(ctypes.Structure):
     'splat_rows', 'split_scratch')]
 
 
-class FrameInputsC(ctypes.Structure):
+class FrameInputsC(_SizedStructure):
   """``ms_frame_inputs``"""
-  _fields_ = [(name, c_void_p) for name in (
+  _fields_ = [('struct_size', ctypes.c_uint32), ('reserved', ctypes.c_uint32)] + [(name, c_void_p) for name in (
     'position', 'log_scaling', 'rotation', 'alpha_logit', 'feature', 'T_camera_world', 'projection',
     'points7', 'depth', 'colours', 'longest_run_host')]
 
 
-class FrameGradsC(ctypes.Structure):
+class FrameGradsC(_SizedStructure):
   """``ms_frame_grads``"""
   _fields_ = [
+    ('struct_size', ctypes.c_uint32), ('reserved', ctypes.c_uint32),
     ('image', c_void_p), ('grad_image', c_void_p),
     ('extra_points7', c_void_p), ('extra_depth', c_void_p), ('extra_colours', c_void_p),
     ('moments', c_void_p), ('deterministic', c_int32), ('stage', c_int32), ('fixed_exp', c_void_p),
@@ -125,9 +140,9 @@ SIGNATURES = {
   'ms_fixed_point_exponents': (c_int, [c_void_p, c_void_p, c_void_p]),
   'ms_raster_bwd_moments': (c_int, [c_void_p] * 6 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
   'ms_raster_moments_finalize': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-  'ms_raster_split_scratch_bytes': (c_size_t, [c_int64, c_int]),
-  'ms_raster_fwd_split': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 4 + [c_int, c_int, c_void_p]),
-  'ms_raster_bwd_moments_split': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+  'ms_raster_split_scratch_bytes': (c_size_t, [c_int64, c_int, c_int, c_int]),
+  'ms_raster_fwd_split': (c_int, [c_void_p] * 4 + [c_int64, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 4 + [c_int, c_int, c_int, c_int, c_void_p]),
+  'ms_raster_bwd_moments_split': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
   'ms_splat_rows_pack': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
   'ms_raster_fwd_rows': (c_int, [c_void_p] * 3 + [c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_void_p]),
   'ms_raster_bwd_moments_rows': (c_int, [c_void_p] * 5 + [c_int, c_int, POINTER(RasterConfigC), c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -176,6 +191,8 @@ def check(rc: int, what: str):
     msg = load().ms_last_error_string().decode('utf-8', 'replace')
     if rc == -2:
       raise NotImplementedError(f"{what}: {msg}")
+    if rc == -4:
+      raise RuntimeError(f"{what}: ABI mismatch between taichi_splatting_amd/_lib.py and libmi355_splat.so: {msg}")
     if rc < 0:
       raise ValueError(f"{what}: {msg}")
     raise RuntimeError(f"{what}: HIP error {rc}: {msg}")

@@ -43,6 +43,14 @@ static FrameGeom frame_geom(const ms_frame_desc* d) {
 
 static int check_desc(const ms_frame_desc* d, const char* who) {
   if (!d) { set_error("%s: desc is null", who); return MS_ERR_BAD_ARG; }
+  // the caller's header: another struct size or ABI generation means its fields are not where this library reads them
+  if (d->struct_size != sizeof(ms_frame_desc) || MS_ABI_GENERATION(d->abi_version) != MS_ABI_GENERATION(MS_VERSION)) {
+    set_error("%s: ms_frame_desc of another ABI (struct_size %u, abi_version %u; this library: %u, %d) — set desc.struct_size = "
+              "sizeof(ms_frame_desc) and desc.abi_version = MS_VERSION of the include/mi355_splat.h you compile against",
+              who, d->struct_size, d->abi_version, (unsigned)sizeof(ms_frame_desc), MS_VERSION);
+    return MS_ERR_ABI;
+  }
+  if (d->split_long_runs < 0 || d->split_seg_len < 0) { set_error("%s: negative split parameter", who); return MS_ERR_BAD_ARG; }
   if (d->n < 0 || d->k_capacity < 0) { set_error("%s: negative size", who); return MS_ERR_BAD_ARG; }
   if (d->n >= (1ll << 31) || d->k_capacity >= (1ll << 31)) { set_error("%s: sizes are int32 indexes (< 2^31)", who); return MS_ERR_BAD_ARG; }
   if (d->image_w <= 0 || d->image_h <= 0) { set_error("%s: bad image size", who); return MS_ERR_BAD_ARG; }
@@ -77,6 +85,28 @@ static bool frame_uses_rows(const ms_frame_desc* d) {
 static bool frame_uses_split(const ms_frame_desc* d) {
   return d->split_long_runs != 0 && d->n > 0 && d->k_capacity > 0 && raster_uses_splat_rows(&d->raster, d->f, d->dtype);
 }
+// split_long_runs = 1: the default threshold; > 1: the threshold itself; split_seg_len = 0: the default segment length
+static SplitParams frame_split_params(const ms_frame_desc* d) {
+  return split_params(d->raster.tile_size, d->split_long_runs, d->split_seg_len);
+}
+
+static int check_inputs(const ms_frame_inputs* in, const char* who) {
+  if (!in) { set_error("%s: inputs are null", who); return MS_ERR_BAD_ARG; }
+  if (in->struct_size != sizeof(ms_frame_inputs)) {
+    set_error("%s: ms_frame_inputs of another ABI (struct_size %u, this library: %u)", who, in->struct_size, (unsigned)sizeof(ms_frame_inputs));
+    return MS_ERR_ABI;
+  }
+  return 0;
+}
+
+static int check_grads(const ms_frame_grads* g, const char* who) {
+  if (!g) { set_error("%s: grads are null", who); return MS_ERR_BAD_ARG; }
+  if (g->struct_size != sizeof(ms_frame_grads)) {
+    set_error("%s: ms_frame_grads of another ABI (struct_size %u, this library: %u)", who, g->struct_size, (unsigned)sizeof(ms_frame_grads));
+    return MS_ERR_ABI;
+  }
+  return 0;
+}
 
 struct Carve {
   size_t off = 0;
@@ -108,7 +138,7 @@ static void frame_layout(const ms_frame_desc* d, ms_frame_layout* L) {
   L->scratch_n_bytes = scratch_n.off;
 
   L->overlap_to_point = keep_k.take(k * 4);
-  L->split_scratch = keep_k.take(frame_uses_split(d) ? split_scratch_bytes(d->k_capacity, d->raster.tile_size) : 0);
+  L->split_scratch = keep_k.take(frame_uses_split(d) ? split_scratch_bytes(d->k_capacity, d->raster.tile_size, frame_split_params(d)) : 0);
   L->keep_k_bytes = keep_k.off;
 
   // 8 byte keys (tile << 32 | depth key) of the direct-order mapper; the pre-sort path (MS_MAPPER=presort) uses half
@@ -224,6 +254,7 @@ static int frame_project_impl(const ms_frame_desc* desc, const ms_frame_inputs* 
 
 extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_project"));
+  MS_TRY(check_inputs(in, "ms_frame_project"));
   MS_CHECK_ARG(in && keep_n, "null pointer");
   return frame_project_impl(desc, in, keep_n, true, true, stream, "ms_frame_project");
 }
@@ -231,6 +262,7 @@ extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs
 extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
                                       void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_project_count"));
+  MS_TRY(check_inputs(in, "ms_frame_project_count"));
   MS_CHECK_ARG(in && keep_n && scratch_n, "null pointer");
   const ms_frame_desc& d = *desc;
   const FrameGeom g = frame_geom(desc);
@@ -296,6 +328,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
                                    void* keep_k, void* scratch_k, void* out_image, void* out_alpha,
                                    void* out_visibility, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_map_raster"));
+  MS_TRY(check_inputs(in, "ms_frame_map_raster"));
   MS_CHECK_ARG(in && keep_n && scratch_n && out_image && out_alpha, "null pointer");
   const ms_frame_desc& d = *desc;
   const FrameGeom g = frame_geom(desc);
@@ -359,7 +392,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   MS_CHECK_ARG(d.n == 0 || colours != nullptr, "colours are null");
   SplitScratch split{};
   const bool cut = frame_uses_split(desc) && keep_k != nullptr;
-  if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size);
+  if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size, frame_split_params(desc));
   return raster_fwd_launch(points7, colours, frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr, ranges, o2p,
                            d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha, out_visibility, g.row_begin, g.row_end,
                            d.dtype, stream, cut ? &split : nullptr, in->longest_run_host);
@@ -368,6 +401,8 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
 extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
                                  const ms_frame_grads* gr, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_backward"));
+  MS_TRY(check_inputs(in, "ms_frame_backward"));
+  MS_TRY(check_grads(gr, "ms_frame_backward"));
   MS_CHECK_ARG(in && keep_n && gr, "null pointer");
   MS_CHECK_ARG(gr->stage == MS_BACKWARD_GAUSSIANS || (gr->image && gr->grad_image), "null image / grad_image");
   const ms_frame_desc& d = *desc;
@@ -409,7 +444,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     // the segments of long tile runs start from the states the forward of THIS frame left in keep_k
     SplitScratch split{};
     const bool cut = frame_uses_split(desc) && keep_k != nullptr;
-    if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size);
+    if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size, frame_split_params(desc));
     MS_TRY(raster_bwd_moments_launch(points7, colours, ranges, o2p, gr->image, gr->grad_image, d.image_w, d.image_h, &d.raster,
                                      (float*)gr->moments, gr->deterministic, gr->fixed_exp, g.row_begin, g.row_end,
                                      gr->grad_image_broadcast, s,

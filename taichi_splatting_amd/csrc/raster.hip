@@ -598,23 +598,25 @@ extern "C" int ms_raster_fwd(const void* points7, const void* features, const in
                            out_alpha, out_visibility, tile_row_begin, tile_row_end, dtype, stream);
 }
 
-extern "C" size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size) {
-  if (k_capacity < 0 || (tile_size != 8 && tile_size != 16 && tile_size != 32)) return 0;
-  return split_scratch_bytes(k_capacity, tile_size);
+extern "C" size_t ms_raster_split_scratch_bytes(int64_t k_capacity, int tile_size, int split_min_run, int split_seg_len) {
+  if (k_capacity < 0 || (tile_size != 8 && tile_size != 16 && tile_size != 32) || split_min_run < 0 || split_seg_len < 0) return 0;
+  return split_scratch_bytes(k_capacity, tile_size, split_params(tile_size, split_min_run, split_seg_len));
 }
 
 extern "C" int ms_raster_fwd_split(const float* points7, const float* features, const int32_t* tile_ranges,
                                    const int32_t* overlap_to_point, int64_t k_capacity, int image_w, int image_h,
                                    const ms_raster_config* cfg, float* out_image, float* out_alpha,
-                                   float* out_visibility, void* split_scratch, int tile_row_begin, int tile_row_end,
-                                   void* stream) {
-  MS_CHECK_ARG(cfg && split_scratch && k_capacity >= 0, "null pointer / negative capacity");
+                                   float* out_visibility, void* split_scratch, int split_min_run, int split_seg_len,
+                                   int tile_row_begin, int tile_row_end, void* stream) {
+  MS_CHECK_ARG(cfg && split_scratch && k_capacity >= 0 && k_capacity < (1ll << 31), "null pointer / capacity outside [0, 2^31)");
+  MS_CHECK_ARG(split_min_run >= 0 && split_seg_len >= 0, "negative split parameter");
   MS_CHECK_ARG((reinterpret_cast<uintptr_t>(split_scratch) & 255) == 0, "split_scratch must be 256-byte aligned");
   if (!raster_uses_splat_rows(cfg, 3, MS_F32)) {
     set_error("ms_raster_fwd_split: float32 RGB, plain pdf, alpha blending");
     return MS_ERR_UNSUPPORTED;
   }
-  const SplitScratch sc = split_scratch_carve(split_scratch, k_capacity, cfg->tile_size);
+  const SplitScratch sc = split_scratch_carve(split_scratch, k_capacity, cfg->tile_size,
+                                              split_params(cfg->tile_size, split_min_run, split_seg_len));
   return raster_fwd_launch(points7, features, nullptr, tile_ranges, overlap_to_point, image_w, image_h, 3, cfg, out_image,
                            out_alpha, out_visibility, tile_row_begin, tile_row_end, MS_F32, stream, &sc, nullptr);
 }

@@ -204,7 +204,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   int tile_id, quarter = 0, seg_start = 0, seg_end = 0;
   if constexpr (SEGS) {
     static_assert(SPLIT == 1, "segments of whole tiles");
-    if ((int)blockIdx.x >= rp.split_counts[0]) return;
+    if (rp.split_counts[2] != 0 || (int)blockIdx.x >= rp.split_counts[0]) return;   // (a void plan: raster_fast.hip)
     const int4 item = rp.split_items[blockIdx.x];
     tile_id = item.x; seg_start = item.y; seg_end = item.z;
   } else {
@@ -253,7 +253,8 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
 
   const int start = SEGS ? seg_start : ranges[tile_id * 2 + 0], end = SEGS ? seg_end : ranges[tile_id * 2 + 1];
   if (end <= start) return;        // (uniform over the workgroup; the staging below reads the tile's list unguarded)
-  if (!SEGS && rp.split_min_run > 0 && end - start > rp.split_min_run) return;   // the segment launch has this tile
+  // the segment launch has this tile (unless the forward's plan overflowed: every tile then is its per-tile workgroup's)
+  if (!SEGS && rp.split_min_run > 0 && end - start > rp.split_min_run && rp.split_counts[2] == 0) return;
 
   // equal batches: as many as it takes to stay near BATCH_TARGET (rounded to nearest), never above BATCH
   const int total = end - start;
@@ -920,7 +921,7 @@ static int launch_scan_backward(const float* points7, const float* features,
   rp.num_tiles = (tile_row_end - tile_row_begin) * tiles_wide;
   if (split && ts == 32 && tile32_quarters()) split = nullptr;     // (the quarter variant walks whole tile lists)
   if (split) {
-    rp.split_min_run = SPLIT_MIN_RUN;
+    rp.split_min_run = split->min_run;
     rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
   }
 #define MS_GO(TS, HEUR, SPLIT, ROWS) raster_bwd_scan_kernel<TS, HEUR, SPLIT, ROWS>                               \
@@ -997,10 +998,18 @@ extern "C" int ms_raster_bwd_moments_split(const float* points7, const float* fe
                                            const int32_t* overlap_to_point, int64_t k_capacity, const float* image,
                                            const float* grad_image, int image_w, int image_h,
                                            const ms_raster_config* cfg, float* moments, int deterministic,
-                                           const int32_t* fixed_exp, const void* split_scratch, int tile_row_begin,
-                                           int tile_row_end, void* stream) {
+                                           const int32_t* fixed_exp, const void* split_scratch, int split_min_run,
+                                           int split_seg_len, int tile_row_begin, int tile_row_end, void* stream) {
   MS_CHECK_ARG(cfg && points7 && features && tile_ranges && image && grad_image && moments && split_scratch, "null pointer");
-  const SplitScratch sc = split_scratch_carve(const_cast<void*>(split_scratch), k_capacity, cfg->tile_size);
+  MS_CHECK_ARG(k_capacity >= 0 && k_capacity < (1ll << 31), "k_capacity must be in [0, 2^31)");
+  MS_CHECK_ARG(split_min_run >= 0 && split_seg_len >= 0, "negative split parameter");
+  MS_CHECK_ARG((reinterpret_cast<uintptr_t>(split_scratch) & 255) == 0, "split_scratch must be 256-byte aligned");
+  if (cfg->tile_size != 8 && cfg->tile_size != 16 && cfg->tile_size != 32) {
+    set_error("ms_raster_bwd_moments_split: tile_size must be 8, 16 or 32 (got %d)", cfg->tile_size);
+    return MS_ERR_UNSUPPORTED;
+  }
+  const SplitScratch sc = split_scratch_carve(const_cast<void*>(split_scratch), k_capacity, cfg->tile_size,
+                                              split_params(cfg->tile_size, split_min_run, split_seg_len));
   return launch_scan_backward(points7, features, tile_ranges, overlap_to_point, image, grad_image, image_w, image_h, cfg,
                               moments, deterministic, fixed_exp, tile_row_begin, tile_row_end, (hipStream_t)stream,
                               "ms_raster_bwd_moments_split", 0, nullptr, &sc);

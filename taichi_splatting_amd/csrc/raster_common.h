@@ -18,7 +18,8 @@ struct FastParams {
   // per-segment launch, which reads the plan
   int split_min_run;
   const int4* split_items;        // (tile, first entry, last entry + 1, index of the tile's first item)
-  const int32_t* split_counts;    // [0] items, [1] long tiles, [2] plan overflow (never: the capacities are bounds)
+  const int32_t* split_counts;    // [0] items, [1] long tiles, [2] plan overflow (capacities are bounds for k_capacity >= K;
+                                  // a caller that lied about K: every tile falls back to its per-tile workgroup)
   float4* split_state;            // (item, pixel in the forward kernel's thread order): forward (C, P) of the segment,
                                   // then (colour in front of the segment, transmittance at its start)
   int32_t* long_run_word;         // pinned host word (may be NULL): the length of a run above SPLIT_MIN_RUN is noted there
@@ -33,35 +34,48 @@ struct FastParams {
 // segment s: the colour in front of it and the transmittance there (backward.py:131-136 keeps exactly this running
 // state).  No gate depends on T in the forward; the backward's saturation test (T against 1 - saturate_threshold)
 // sees a T that was rounded in a different order — the same class of deviation as a pair on the blend gate.
-constexpr int SPLIT_MIN_RUN = 16384;   // runs above this are cut ...
+constexpr int SPLIT_MIN_RUN = 16384;   // DEFAULT: runs above this are cut (and reported to the host: long_run_word) ...
 constexpr int SPLIT_MAX_SEG = 256;     // ... into at most this many segments per tile ...
-// ... of at least this many entries (a multiple of every batch size).  Short segments = many workgroups: the pile-up's
+// ... of at least seg_len entries (a multiple of 256: of every batch size).  Short segments = many workgroups: the pile-up's
 // 2.35 M overlaps make 576 workgroups at 4096 entries (2 per CU: one wave per SIMD, latency-bound) and 2300 at 1024.
-// A tile-32 workgroup has 16 waves and 16 KB of state per segment: four times the length.  MS_SPLIT_SEG in the
-// environment (read once) overrides, for measurements.
-static inline int split_seg_len(int tile_size) {
+// A tile-32 workgroup has 16 waves and 16 KB of state per segment: four times the length.
+// Both numbers are RUN-TIME parameters of a (forward, backward) pair since round 6 (ms_raster_fwd_split's
+// split_min_run / split_seg_len, ms_frame_desc.split_long_runs / split_seg_len; 0 = the defaults here), so that the
+// oracle can reach the segment kernels on scenes it finishes in seconds.  MS_SPLIT_SEG in the environment (read once)
+// overrides the default segment length, for measurements.
+static inline int split_default_seg_len(int tile_size) {
   static const int forced = [] { const char* e = getenv("MS_SPLIT_SEG"); const int v = e ? atoi(e) : 0; return v >= 256 ? (v + 255) & ~255 : 0; }();
   if (forced) return forced;
   return tile_size == 32 ? 4096 : 1024;
 }
+struct SplitParams { int min_run, seg_len; };
+// min_run_req <= 1 / seg_req <= 0: the defaults.  A run is cut only if it is longer than min_run, and never below 256
+static inline SplitParams split_params(int tile_size, int min_run_req, int seg_req) {
+  SplitParams sp;
+  sp.min_run = min_run_req > 1 ? (min_run_req < 256 ? 256 : min_run_req) : SPLIT_MIN_RUN;
+  sp.seg_len = seg_req > 0 ? ((seg_req + 255) & ~255) : split_default_seg_len(tile_size);
+  return sp;
+}
 // the scratch block of one (forward, backward) pair: plan + per-(item, pixel) state, carved from caller memory
 struct SplitScratch {
-  int32_t* counts;      // 4 words
+  int32_t* counts;      // 4 words: [0] items, [1] long tiles, [2] plan overflow, [3] unused
   int4* long_tiles;     // long_cap x (tile, first item, segments, 0)
   int4* items;          // item_cap
   float4* state;        // item_cap x tile_size^2
   int64_t long_cap, item_cap;
+  int min_run, seg_len;
 };
-static inline int64_t split_long_capacity(int64_t k_capacity) { return k_capacity / SPLIT_MIN_RUN + 1; }
-static inline int64_t split_item_capacity(int64_t k_capacity, int tile_size) { return k_capacity / split_seg_len(tile_size) + split_long_capacity(k_capacity) + 1; }
-static inline size_t split_scratch_bytes(int64_t k_capacity, int tile_size) {
-  const size_t lc = (size_t)split_long_capacity(k_capacity), ic = (size_t)split_item_capacity(k_capacity, tile_size);
+static inline int64_t split_long_capacity(int64_t k_capacity, SplitParams sp) { return k_capacity / sp.min_run + 1; }
+static inline int64_t split_item_capacity(int64_t k_capacity, SplitParams sp) { return k_capacity / sp.seg_len + split_long_capacity(k_capacity, sp) + 1; }
+static inline size_t split_scratch_bytes(int64_t k_capacity, int tile_size, SplitParams sp) {
+  const size_t lc = (size_t)split_long_capacity(k_capacity, sp), ic = (size_t)split_item_capacity(k_capacity, sp);
   return 256 + ((lc * 16 + 255) & ~(size_t)255) + ((ic * 16 + 255) & ~(size_t)255) + ic * (size_t)tile_size * tile_size * 16;
 }
-static inline SplitScratch split_scratch_carve(void* base, int64_t k_capacity, int tile_size) {
+static inline SplitScratch split_scratch_carve(void* base, int64_t k_capacity, int tile_size, SplitParams sp) {
   SplitScratch sc;
   char* p = (char*)base;
-  sc.long_cap = split_long_capacity(k_capacity); sc.item_cap = split_item_capacity(k_capacity, tile_size);
+  sc.min_run = sp.min_run; sc.seg_len = sp.seg_len;
+  sc.long_cap = split_long_capacity(k_capacity, sp); sc.item_cap = split_item_capacity(k_capacity, sp);
   sc.counts = (int32_t*)p; p += 256;
   sc.long_tiles = (int4*)p; p += ((size_t)sc.long_cap * 16 + 255) & ~(size_t)255;
   sc.items = (int4*)p; p += ((size_t)sc.item_cap * 16 + 255) & ~(size_t)255;

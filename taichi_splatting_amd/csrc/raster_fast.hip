@@ -51,7 +51,9 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 
   int tile_id, start, end;
   if constexpr (SEGS) {
-    if ((int)blockIdx.x >= rp.split_counts[0]) return;
+    // (a plan that overflowed its capacities — a caller that passed k_capacity below the real overlap count — is not
+    // executed: the per-tile launch has rendered every tile)
+    if (rp.split_counts[2] != 0 || (int)blockIdx.x >= rp.split_counts[0]) return;
     const int4 item = rp.split_items[blockIdx.x];
     tile_id = item.x; start = item.y; end = item.z;
   } else {
@@ -60,11 +62,11 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
     if (local_tile < 0) return;
     tile_id = rp.tile_begin + local_tile;
     start = ranges[tile_id * 2 + 0]; end = ranges[tile_id * 2 + 1];
-    if (end - start > SPLIT_MIN_RUN) {
-      // a scene shape that shows such a run is rendered with the segment launches from its next frame on (frame.py)
-      if (rp.long_run_word && threadIdx.x == 0) *rp.long_run_word = end - start;
-      if (rp.split_min_run > 0) return;                  // this frame already is: the segment launch has the tile
-    }
+    // a scene shape that shows a run above the default limit is rendered with the segment launches from its next frame
+    // on (frame.py)
+    if (end - start > SPLIT_MIN_RUN && rp.long_run_word && threadIdx.x == 0) *rp.long_run_word = end - start;
+    // this frame already is: the segment launch has the tile (unless the plan overflowed, see above)
+    if (rp.split_min_run > 0 && end - start > rp.split_min_run && rp.split_counts[2] == 0) return;
   }
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -92,6 +94,9 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   const bool stager = t < BATCH;
   if (stager && start + t < end) raw = load_raw<ROWS>(points, feats, o2p[start + t]);
   if (stager && start + BATCH + t < end) next_id = o2p[start + BATCH + t];
+  // (the spent-tile exit below may leave the loop before the first batch is staged — the second walk of a segment that
+  // sits behind an opaque surface: the flush behind the loop must then find zeros, not whatever LDS held)
+  if (VIS && stager) s_vis[t] = 0.0f;
 
   for (int begin = start; begin < end; begin += BATCH) {
     const int count = (end - begin) < BATCH ? (end - begin) : BATCH;
@@ -204,19 +209,21 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 // >= seg_len entries (multiples of 256: every batch size divides them).  counts[0..2] are zero on entry.  The item
 // order depends on the order of the atomics; nothing else does (results are addressed by item).
 __global__ void __launch_bounds__(256)
-split_plan_kernel(const int32_t* __restrict__ ranges, int tile_begin, int num_tiles, int seg_len, int item_cap, int long_cap,
-                  int32_t* __restrict__ counts, int4* __restrict__ long_tiles, int4* __restrict__ items) {
+split_plan_kernel(const int32_t* __restrict__ ranges, int tile_begin, int num_tiles, int min_run, int seg_len, int item_cap,
+                  int long_cap, int32_t* __restrict__ counts, int4* __restrict__ long_tiles, int4* __restrict__ items) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num_tiles) return;
   const int tile = tile_begin + i;
   const int start = ranges[tile * 2 + 0], end = ranges[tile * 2 + 1], run = end - start;
-  if (run <= SPLIT_MIN_RUN) return;
+  if (run <= min_run) return;
   int nseg = (run + seg_len - 1) / seg_len;
   if (nseg > SPLIT_MAX_SEG) nseg = SPLIT_MAX_SEG;
   const int seg = ((run + nseg - 1) / nseg + 255) & ~255;
   nseg = (run + seg - 1) / seg;
   const int first = atomicAdd(&counts[0], nseg), li = atomicAdd(&counts[1], 1);
-  if (first + nseg > item_cap || li >= long_cap) { counts[2] = 1; return; }     // (the capacities are upper bounds)
+  // the capacities are upper bounds when k_capacity >= K; otherwise the whole plan is void (the kernels that read it
+  // test counts[2] first and the per-tile launches take every tile)
+  if (first + nseg > item_cap || li >= long_cap) { counts[2] = 1; return; }
   long_tiles[li] = make_int4(tile, first, nseg, 0);
   for (int k = 0; k < nseg; ++k) {
     const int b = start + k * seg, e = b + seg < end ? b + seg : end;
@@ -231,7 +238,7 @@ __global__ void __launch_bounds__(TS * TS)
 split_combine_kernel(FastParams rp, const int4* __restrict__ long_tiles, float* __restrict__ image,
                      float* __restrict__ image_alpha) {
   using G = TileGeom<TS>;
-  if ((int)blockIdx.x >= rp.split_counts[1]) return;
+  if (rp.split_counts[2] != 0 || (int)blockIdx.x >= rp.split_counts[1]) return;
   const int4 lt = long_tiles[blockIdx.x];
   const int tile_id = lt.x, first = lt.y, nseg = lt.z;
   const int tile_u = tile_id % rp.tiles_wide, tile_v = tile_id / rp.tiles_wide;
@@ -442,12 +449,12 @@ bool ms_raster_fwd_fast(const void* points, const void* feats, const int32_t* ra
   // know the transmittance in front of it before the composition pass has run)
   const bool cut = split != nullptr;
   if (cut) {
-    rp.split_min_run = SPLIT_MIN_RUN;
+    rp.split_min_run = split->min_run;
     rp.split_items = split->items; rp.split_counts = split->counts; rp.split_state = split->state;
     (void)hipMemsetAsync(split->counts, 0, 4 * sizeof(int32_t), s);
     split_plan_kernel<<<dim3((unsigned)((num_tiles + 255) / 256)), dim3(256), 0, s>>>(
-        ranges, rp.tile_begin, num_tiles, split_seg_len(cfg->tile_size), (int)split->item_cap, (int)split->long_cap, split->counts, split->long_tiles,
-        split->items);
+        ranges, rp.tile_begin, num_tiles, split->min_run, split->seg_len, (int)split->item_cap, (int)split->long_cap,
+        split->counts, split->long_tiles, split->items);
   }
   const dim3 grid(xcd_grid<FWD_XCD_CHUNK>(rp.num_tiles, 1));
 #define MS_GO3(TS, VIS, ROWS)                                                                                   \

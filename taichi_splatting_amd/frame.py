@@ -63,6 +63,13 @@ MOMENTS_LRU = 4           # accumulator buffers kept per device (scene sizes / s
 K_SLOTS = 64              # pinned K words per device; a frame holds one from its forward until it has looked at K
 GRAPH_K_WORDS = 1024      # pinned K words per device for frames captured into HIP graphs
 SPLIT_LONG_RUNS = os.environ.get('MS_SPLIT_LONG_RUNS', '1') not in ('', '0')   # A/B switch of the long-run segments
+# run-time parameters of the segments (ms_frame_desc.split_long_runs / split_seg_len): a run is cut when it is longer than
+# SPLIT_MIN_RUN entries (0: the library's default, 16 384) into segments of >= SPLIT_SEG_LEN entries (0: default);
+# SPLIT_ALWAYS: every frame carries the segment launches, not only shapes that showed a long run (tests reach the segment
+# kernels on scenes the oracle finishes in seconds this way: set_split_policy)
+SPLIT_MIN_RUN = int(os.environ.get('MS_SPLIT_MIN_RUN', '0'))
+SPLIT_SEG_LEN = int(os.environ.get('MS_SPLIT_SEG_LEN', '0'))
+SPLIT_ALWAYS = os.environ.get('MS_SPLIT_ALWAYS', '0') not in ('', '0')
 BROADCAST_GRAD = os.environ.get('MS_BROADCAST_GRAD', '1') not in ('', '0')   # A/B switch of grad_image_broadcast
 STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
@@ -99,6 +106,13 @@ def set_overlap_capacity(n: int, image_size, config: RasterConfig, capacity: int
   _choose_mapper(key, int(capacity / K_SLACK), n)
   if not torch.cuda.is_current_stream_capturing():
     _k_ring(dev)               # pinned words must exist before a capture starts
+
+
+def set_split_policy(min_run: int = 0, seg_len: int = 0, always: bool = False):
+  """Parameters of the long-run segments for the frames enqueued from now on (process-wide; (0, 0, False) = defaults)."""
+  global SPLIT_MIN_RUN, SPLIT_SEG_LEN, SPLIT_ALWAYS
+  assert min_run >= 0 and seg_len >= 0
+  SPLIT_MIN_RUN, SPLIT_SEG_LEN, SPLIT_ALWAYS = int(min_run), int(seg_len), bool(always)
 
 
 def _choose_mapper(key, k_total: int, n: int):
@@ -313,10 +327,17 @@ def _drop_moments():
   are dropped and reallocated on demand."""
   with _lock:
     for key in list(_moments):
-      if key in _moments_pinned:
-        _moments[key].zero_()
-      else:
+      if key not in _moments_pinned:
         del _moments[key]
+        continue
+      buf = _moments[key]
+      if torch.cuda.is_current_stream_capturing():
+        continue              # (a failure inside a capture: the capture is lost anyway, and a fill must not join it)
+      # on the buffer's OWN stream (key[1]): the graph that replays into it runs there, and a fill on whatever stream
+      # is current could race with a replay in flight (ADVICE round 5)
+      own = torch.cuda.ExternalStream(key[1], device=buf.device) if key[1] else torch.cuda.default_stream(buf.device)
+      with torch.cuda.stream(own):
+        buf.zero_()
 
 
 class FrameState:
@@ -407,7 +428,10 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
     # a shape that showed a run above LONG_RUN_LIMIT also has its long runs rasterized in segments (the raster forward
     # reports such runs through the same word on either mapper sequence)
-    desc.split_long_runs = 1 if (SPLIT_LONG_RUNS and key in _presort_sticky) else 0
+    # (field value 1 = the default threshold, > 1 = the threshold itself; the library raises thresholds below 256)
+    split_on = SPLIT_LONG_RUNS and (SPLIT_ALWAYS or key in _presort_sticky)
+    desc.split_long_runs = (max(2, SPLIT_MIN_RUN) if SPLIT_MIN_RUN > 0 else 1) if split_on else 0
+    desc.split_seg_len = SPLIT_SEG_LEN
   if capturing and capacity == 0:
     raise RuntimeError(f"{what} under HIP-graph capture: the overlap-list capacity of this scene shape is unknown; "
                        "render one eager frame first or call frame.set_overlap_capacity(...)")

@@ -30,6 +30,13 @@ def get_running_vis(state: dict, n: int, device: torch.device) -> torch.Tensor:
   return PointState(state).per_point('running_vis', n, device)
 
 
+def exp_lerp(t, a, b):
+  """``log(lerp(t, exp(a), exp(b)))`` without overflow: interpolation of two log-domain values in the linear domain
+  (reference optim/visibility_aware.py:19-22; plain eager torch here, the reference compiles it)."""
+  top = torch.maximum(a, b)
+  return top + torch.log(torch.lerp(torch.exp(a - top), torch.exp(b - top), t))
+
+
 def lerp(t, a, b):
   """Value a fraction ``t`` of the way from ``a`` to ``b``."""
   return torch.lerp(torch.as_tensor(a), torch.as_tensor(b), t) if torch.is_tensor(t) else a + t * (b - a)
@@ -45,7 +52,7 @@ def power_lerp(t, a, b, k=2):
 
 
 def update_visibility(running_vis: torch.Tensor, visibility: torch.Tensor, indexes: torch.Tensor,
-                      total_weight: Optional[torch.Tensor] = None, beta: float = 0.9, eps: float = 1e-12) -> torch.Tensor:
+                      total_weight: torch.Tensor, beta: float = 0.9, eps: float = 1e-12) -> torch.Tensor:
   """Updates ``running_vis[indexes]`` in place and returns the step weights (``total_weight`` is unused, as in the
   reference)."""
   return _track_visibility(running_vis, visibility, indexes, beta, floor=eps)

@@ -306,7 +306,7 @@ def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuri
   k, (w, h) = o2p.shape[0], size
   cfg_c, stream = _lib.raster_config_c(cfg), _lib.current_stream(torch.device(DEV))
   th = (h + tile - 1) // tile
-  scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, tile),), dtype=torch.uint8, device=DEV)
+  scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, tile, 0, 0),), dtype=torch.uint8, device=DEV)
   assert scratch.data_ptr() % 256 == 0
 
   def forward(split):
@@ -314,7 +314,7 @@ def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuri
     vis = torch.zeros(n, device=DEV) if visibility else None
     if split:
       _lib.check(lib.ms_raster_fwd_split(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h, cfg_c,
-                                         image.data_ptr(), alpha.data_ptr(), _lib.ptr(vis), scratch.data_ptr(), 0, th, stream),
+                                         image.data_ptr(), alpha.data_ptr(), _lib.ptr(vis), scratch.data_ptr(), 0, 0, 0, th, stream),
                  "fwd split")
     else:
       _lib.check(lib.ms_raster_fwd(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_c,
@@ -339,7 +339,7 @@ def test_long_tile_runs_cut_into_segments_match_the_per_tile_kernels(tile, heuri
     if split:
       _lib.check(lib.ms_raster_bwd_moments_split(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k,
                                                  image.data_ptr(), G.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None,
-                                                 scratch.data_ptr(), 0, th, stream), "bwd split")
+                                                 scratch.data_ptr(), 0, 0, 0, th, stream), "bwd split")
     else:
       _lib.check(lib.ms_raster_bwd_moments(p.data_ptr(), f.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), image.data_ptr(),
                                            G.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None, 0, th, stream), "bwd")

@@ -1,4 +1,6 @@
 """Round 5, CPU: the reference's module-level names of optim/visibility_aware.py, frame bookkeeping under failure."""
+import math
+
 import pytest
 import torch
 
@@ -23,3 +25,12 @@ def test_visibility_aware_public_helpers_match_the_reference_signatures():
   assert torch.equal(scattered[idx], seen) and int((scattered != 0).sum()) == 30 and scattered.shape == before.shape
   state = {}
   assert get_running_vis(state, 5, torch.device('cpu')).shape == (5,) and 'running_vis' in state
+  # exp_lerp (reference :19-22): log(lerp(t, e^a, e^b)), finite where the naive form overflows; total_weight is a
+  # required positional argument of update_visibility, as in the reference
+  from taichi_splatting_amd.optim.visibility_aware import exp_lerp
+  a, b = torch.randn(50), torch.randn(50)
+  assert torch.allclose(exp_lerp(0.3, a, b), torch.log(torch.lerp(torch.exp(a), torch.exp(b), 0.3)), atol=1e-6)
+  big = exp_lerp(0.5, torch.tensor([1000.0]), torch.tensor([998.0]))
+  assert torch.isfinite(big).all() and abs(float(big) - (1000.0 + math.log(0.5 + 0.5 * math.exp(-2.0)))) < 1e-3
+  with pytest.raises(TypeError):
+    update_visibility(running, seen, idx)

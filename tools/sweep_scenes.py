@@ -130,16 +130,16 @@ def measure(spec, dev):
     long_runs = int(runs.max()) > 16384
     out['raster'] = 'segments' if long_runs else 'per tile'
     if long_runs:
-      scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, 16),), dtype=torch.uint8, device=dev)
+      scratch = torch.empty((lib.ms_raster_split_scratch_bytes(k, 16, 0, 0),), dtype=torch.uint8, device=dev)
 
       def fwd_split():
         _lib.check(lib.ms_raster_fwd_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k, w, h,
-                                           cfg_c, image.data_ptr(), alpha.data_ptr(), None, scratch.data_ptr(), 0, th, stream), "fwd split")
+                                           cfg_c, image.data_ptr(), alpha.data_ptr(), None, scratch.data_ptr(), 0, 0, 0, th, stream), "fwd split")
 
       def bwd_split():
         _lib.check(lib.ms_raster_bwd_moments_split(g2d_c.data_ptr(), feats_c.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), k,
                                                    image.data_ptr(), grad_image.data_ptr(), w, h, cfg_c, mom.data_ptr(), 0, None,
-                                                   scratch.data_ptr(), 0, th, stream), "bwd split")
+                                                   scratch.data_ptr(), 0, 0, 0, th, stream), "bwd split")
       out['raster_fwd_per_tile_ms'] = out['raster_fwd_ms']
       out['raster_fwd_ms'] = cuda_ms(fwd_split)
 
