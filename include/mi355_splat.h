@@ -295,6 +295,11 @@ int ms_raster_bwd_moments_split(const float* points7, const float* features, con
                                 float* moments, int deterministic, const int32_t* fixed_exp, const void* split_scratch,
                                 int split_min_run, int split_seg_len, int tile_row_begin, int tile_row_end, void* stream);
 
+/* Measurement hook: the NEXT launch of the product raster backward (ms_raster_bwd_moments*, ms_frame_backward on the
+ * moments path) records the two hipEvent_t around its per-tile kernel on the stream it is launched on, then disarms.
+ * bench.py times the dominant kernel INSIDE whole frames with it (roofline.kernel_ms); NULL, NULL disarms. */
+int ms_probe_raster_bwd(void* start_event, void* stop_event);
+
 #define MS_SPLAT_ROW 16
 int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
                        void* stream);
@@ -484,6 +489,43 @@ int ms_fractional_update(int kind, int group_type, float* param, const float* gr
                          const float* grad_scale, const float* basis, const float* mask_lr,
                          const float* point_lr, int64_t m_count, int d, float lr, float beta1,
                          float beta2, float eps, float clip, int bias_correction, void* stream);
+
+/* All parameter groups of one optimiser step in ONE launch (round 6; the reference loops over its groups on the host,
+ * optim/fractional.py:176-195, optim/visibility_aware.py:86-104).  Each group is what ms_fractional_update takes;
+ * indexes / weight / total_weight / grad_scale are shared by the groups, as they are in the reference's step().
+ * Rows whose length is a multiple of 4 floats (16-byte aligned arrays) move as 16-byte pieces.  A row with
+ * weight[i] < 0 is skipped; indexes == NULL means rows 0 .. m_count - 1 (both: the dense mode of
+ * ms_optim_visibility_weights).  `groups` is a HOST array. */
+typedef struct ms_optim_group {
+  uint32_t struct_size;            /* sizeof(ms_optim_group) */
+  int32_t group_type;              /* 0 scalar, 1 vector, 2 local_vector */
+  float* param;                    /* (N, d) */
+  const float* grad;               /* (N, d) */
+  float* m;                        /* (N, d) first moment */
+  float* v;                        /* second moment: (N, d) for scalar groups, (N,) otherwise */
+  const float* basis;              /* local_vector: (m_count, d, d), else NULL */
+  const float* mask_lr;            /* (d) or NULL */
+  const float* point_lr;           /* (N) or NULL */
+  int32_t d;
+  int32_t bias_correction;
+  float lr, beta1, beta2, eps;
+  float clip;                      /* < 0: off */
+  float reserved;
+} ms_optim_group;
+int ms_optim_step_groups(int kind, const ms_optim_group* groups, int num_groups, const int64_t* indexes,
+                         const float* weight, const float* total_weight, const float* grad_scale, int64_t m_count,
+                         void* stream);
+
+/* Step weights of the visibility-aware optimisers in one pass (optim/visibility_aware.py:35-52 update_visibility and
+ * :86-104): for the m_count rows listed in indexes, running_vis <- ((1 - beta) v^4 + beta running_vis^4)^(1/4),
+ * out_weight = v / max(running_vis, floor_eps), total_weight += out_weight, out_grad_scale = 1 / (v + vis_smooth)
+ * (out_grad_scale may be NULL).  indexes == NULL (dense mode): row i is point i, and a point with
+ * visibility <= skip_threshold is left untouched and gets out_weight = -1 (which ms_optim_step_groups /
+ * ms_fractional_update skip) — the reference's `visible = (visibility > 1e-8).nonzero()` without the host
+ * synchronisation (examples/fit_image_gaussians.py:118-119). */
+int ms_optim_visibility_weights(const int64_t* indexes, const float* visibility, int64_t m_count, float vis_beta,
+                                float vis_smooth, float floor_eps, float skip_threshold, float* running_vis,
+                                float* total_weight, float* out_weight, float* out_grad_scale, void* stream);
 
 /* ---- Morton codes --------------------------------------------------------------------
  * out_codes[i] = 63-bit Z-order code of points3[i] (N, 3 float32) on the grid of cell size inc3_host anchored at

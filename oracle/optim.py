@@ -65,3 +65,15 @@ def group_update(kind, group_type, param, grad, m, v, indexes, weight, total_wei
   step = torch.where(torch.isfinite(step), step, torch.zeros_like(step))
   param[indexes] -= step * (1 - 1 / torch.exp(2 * weight)).unsqueeze(1)
   return step
+
+
+def visibility_weights(running_vis, visibility, indexes, total_weight, beta, vis_smooth, eps=1e-12):
+  """optim/visibility_aware.py:35-52 (update_visibility: power_lerp of order 4 between the new visibilities and the
+  running ones) and :86-97 of the step: returns (weight, grad_scale) and updates running_vis / total_weight in place."""
+  k = 4
+  a, b = visibility, running_vis[indexes]
+  updated = (a ** k + (b ** k - a ** k) * beta) ** (1 / k)          # lerp(t, x, y) = x + (y - x) t, t = beta
+  running_vis[indexes] = updated
+  weight = visibility / torch.clamp_min(updated, eps)
+  total_weight[indexes] += weight
+  return weight, 1.0 / (visibility + vis_smooth)

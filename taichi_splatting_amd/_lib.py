@@ -106,6 +106,17 @@ class FrameGradsC(_SizedStructure):
   ]
 
 
+class OptimGroupC(ctypes.Structure):
+  """``ms_optim_group``"""
+  _fields_ = [
+    ('struct_size', ctypes.c_uint32), ('group_type', c_int32),
+    ('param', c_void_p), ('grad', c_void_p), ('m', c_void_p), ('v', c_void_p),
+    ('basis', c_void_p), ('mask_lr', c_void_p), ('point_lr', c_void_p),
+    ('d', c_int32), ('bias_correction', c_int32),
+    ('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float), ('clip', c_float), ('reserved', c_float),
+  ]
+
+
 # name -> (restype, argtypes); must list every function declared in include/mi355_splat.h
 SIGNATURES = {
   'ms_version': (c_int, []),
@@ -152,6 +163,9 @@ SIGNATURES = {
   'ms_frame_project_count': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_frame_map_raster': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC)] + [c_void_p] * 8),
   'ms_frame_backward': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, POINTER(FrameGradsC), c_void_p]),
+  'ms_probe_raster_bwd': (c_int, [c_void_p, c_void_p]),
+  'ms_optim_step_groups': (c_int, [c_int, POINTER(OptimGroupC), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+  'ms_optim_visibility_weights': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float] + [c_void_p] * 5),
   'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),
 }
 

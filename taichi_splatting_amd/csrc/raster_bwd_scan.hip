@@ -891,6 +891,14 @@ static bool tile32_quarters() {
   return q;
 }
 
+// Measurement hook (include/mi355_splat.h: ms_probe_raster_bwd): the next launch of the product backward records these two
+// events around its per-tile kernel, on the stream it is launched on — the kernel's duration INSIDE a frame (bench.py).
+static hipEvent_t g_probe_start = nullptr, g_probe_stop = nullptr;
+extern "C" int ms_probe_raster_bwd(void* start_event, void* stop_event) {
+  g_probe_start = (hipEvent_t)start_event; g_probe_stop = (hipEvent_t)stop_event;
+  return 0;
+}
+
 static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,
@@ -947,18 +955,24 @@ static int launch_scan_backward(const float* points7, const float* features,
     return 0;
   }
 #endif
+  const hipEvent_t probe_start = g_probe_start, probe_stop = g_probe_stop;
+  g_probe_start = g_probe_stop = nullptr;                      // one launch per arming
+  if (probe_start) (void)hipEventRecord(probe_start, s);
+#define MS_PROBE_STOP() do { if (probe_stop) (void)hipEventRecord(probe_stop, s); } while (0)
   switch (ts) {
-    case 8: MS_GO_TILE(8, 1, false); if (split) MS_GO_SEGS(8); break;
-    case 16: if (splat_rows) MS_GO_TILE(16, 1, true); else MS_GO_TILE(16, 1, false); if (split) MS_GO_SEGS(16); break;
+    case 8: MS_GO_TILE(8, 1, false); MS_PROBE_STOP(); if (split) MS_GO_SEGS(8); break;
+    case 16: if (splat_rows) MS_GO_TILE(16, 1, true); else MS_GO_TILE(16, 1, false); MS_PROBE_STOP(); if (split) MS_GO_SEGS(16); break;
     default:
       // tile 32: ONE 1024-thread workgroup per tile with 896-splat batches (152 KB LDS), or — MS_TILE32_BWD=quarters —
       // four 16 x 16 quarter workgroups per tile that each stage the whole tile list
       if (tile32_quarters()) MS_GO_TILE(16, 2, false);
       else if (splat_rows) MS_GO_TILE(32, 1, true);
       else MS_GO_TILE(32, 1, false);
+      MS_PROBE_STOP();
       if (split) MS_GO_SEGS(32);
       break;
   }
+#undef MS_PROBE_STOP
 #undef MS_GO_SEGS
 #undef MS_GO_TILE
 #undef MS_GO

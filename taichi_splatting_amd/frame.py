@@ -73,7 +73,21 @@ SPLIT_ALWAYS = os.environ.get('MS_SPLIT_ALWAYS', '0') not in ('', '0')
 BROADCAST_GRAD = os.environ.get('MS_BROADCAST_GRAD', '1') not in ('', '0')   # A/B switch of grad_image_broadcast
 STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
-host_syncs = 0            # forward-pass waits on the overlap total (non-stalling: the frame is already enqueued)
+# Eager frames that will be differentiated look at their overlap total LATE (round 6): the K word stays in its pinned
+# slot and is read at the NEXT frame's entry (or at the first host access to the frame's lists / status), so the backward of
+# frame i is enqueued while frame i's forward still runs and the host can be a whole frame ahead of the GPU — what a
+# HIP-graph replay gets for free.  Only for scene shapes whose capacity has not grown for LAZY_AFTER settled frames; an
+# overflow found late means that frame rendered the background and returned zero gradients: FrameOverflow is raised at
+# the point it is found (as a graph replay does).  MS_STRICT=1 / MS_LAZY_SETTLE=0: every frame waits before it returns.
+LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '1') not in ('', '0')
+LAZY_AFTER = 3
+_stable_frames = {}       # scene-shape key -> settled frames in a row that fitted the remembered capacity
+_unsettled = collections.deque()   # FrameStates whose overlap total the host has not looked at yet (oldest first)
+
+host_syncs = 0            # looks at an overlap total BETWEEN a frame's forward and its backward / return to the caller
+entry_waits = 0           # lazily settled frames whose total was not there yet at the next frame's entry (back-pressure:
+                          # the GPU then has that frame's forward rest and whole backward still queued — it does not idle)
+settles = 0               # looks at an overlap total, of either kind
 point_syncs = 0           # LazyPoints materialisations (host read of the visible count)
 
 
@@ -209,10 +223,11 @@ def _pinned_k(device):
   return slot, word, view, torch.cuda.Event(), ring
 
 
-def _wait_for_k(k_np, k_event) -> int:
+def _wait_for_k(k_np, k_event, at_entry=False) -> int:
   """The host's one wait per eager frame.  Polling the pinned word the K kernel writes returns within microseconds of
   the write; ``Event.synchronize`` (an interrupt-driven sleep) cost 0.3-0.5 ms of wake-up latency per frame, which
   at 1 M gaussians left the GPU idle for a third of the frame."""
+  global host_syncs, entry_waits
   deadline = time.perf_counter() + 2.0
   spins = 0
   while k_np[0] == K_PENDING:
@@ -222,6 +237,10 @@ def _wait_for_k(k_np, k_event) -> int:
       if time.perf_counter() > deadline:    # never seen; a lost write must not hang the caller
         k_event.synchronize()
         break
+  if at_entry:
+    entry_waits += 1 if spins else 0
+  else:
+    host_syncs += 1
   return int(k_np[0])
 
 
@@ -248,6 +267,11 @@ def parked_gc():
 
 
 def release_caches(force: bool = False):
+  settle_all()
+  _release_caches(force)
+
+
+def _release_caches(force: bool = False):
   """Drop what the executor keeps between frames: the persistent moments accumulators (64 B per gaussian), the shared
   identity index lists, the remembered overlap capacities and the pinned K words.  Accumulators whose address a
   captured HIP graph replays into (``FrameGraph`` / ``torch.cuda.graph``) are kept unless ``force`` — freeing them
@@ -260,6 +284,7 @@ def release_caches(force: bool = False):
     if force:
       _moments_pinned.clear()
     _identity.clear()
+    _stable_frames.clear()
     _k_capacity.clear()
     _mapper_mode.clear()
     _presort_sticky.clear()
@@ -353,23 +378,45 @@ class FrameState:
     self.capacity = 0
     self.children = []            # (weakref to a tensor handed out, index list or None, 'points7' | 'colours')
     self.y0 = 0
-    self.pending = None           # eager mode: the wait for K + capacity check, run once by the frame's caller
+    self.pending = None           # eager mode: the look at K + capacity check, run once (by the frame's caller, or later)
+    self.k_peek = None            # numpy view of the frame's pinned K word while `pending` is set
+    self.consumed = False         # a backward pass was enqueued before the frame was settled
+    self.key = None               # scene-shape key
     self.captured = False         # enqueued under HIP-graph capture: k_word / k_view = the pinned word replays write K to
     self.k_word = self.k_view = None
     self.overflowed = 0           # largest overlap total a replay was seen to exceed the capacity with (sticky)
 
   def settle(self):
-    if self.pending is not None:
-      self.pending()
+    """Look at the frame's overlap total (waiting for it if the GPU has not produced it yet) and re-run the emission
+    with larger buffers when it did not fit.  Raises FrameOverflow when that comes too late: the backward pass of the
+    frame was already enqueued on the lists of the overflowed forward."""
+    with _lock:
+      fn, self.pending = self.pending, None      # (taken atomically: a viewer thread may settle the trainer's frames)
+    if fn is not None:
+      fn()
+
+  def settle_if_known(self):
+    """Backward pass of a lazily settled frame: settle only if that costs no wait.  Returns False when the overlap total
+    is not there yet — the backward is then enqueued on the frame as it is (see LAZY_SETTLE)."""
+    if self.pending is None:
+      return True
+    if self.k_peek is not None and int(self.k_peek[0]) == K_PENDING:
+      self.consumed = True          # from here on a re-run of the forward could not repair this frame's gradients
+      return False
+    self.settle()
+    return True
 
   def counters(self) -> torch.Tensor:
+    self.settle()
     return self.keep_n[self.layout.counters:self.layout.counters + 32].view(torch.int32)
 
   def overlap_to_point(self) -> torch.Tensor:
+    self.settle()
     off = self.layout.overlap_to_point
     return self.keep_k[off:off + 4 * self.capacity].view(torch.int32)
 
   def tile_ranges(self) -> torch.Tensor:
+    self.settle()
     off = self.layout.tile_ranges
     ts = self.desc.raster.tile_size
     th, tw = (self.desc.image_h + ts - 1) // ts, (self.desc.image_w + ts - 1) // ts
@@ -406,10 +453,11 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   is re-run with larger buffers in the rare case it did not fit.  Fills ``state`` (layout, keep_k, capacity, k) and
   leaves ``state.pending`` = the settle step (the wait + check) for the caller to run as the LAST thing it does for
   this frame — the later the host looks, the more of its own per-frame work is hidden behind queued GPU work."""
-  global host_syncs
   lib = _lib.load()
   stream = _lib.current_stream(device)
   capturing = torch.cuda.is_current_stream_capturing()
+  if not capturing:
+    settle_all()                 # earlier frames of this process: their words are (almost always) written long ago
   # the scene-shape caches are shared by every thread that renders (a viewer next to a trainer): looked up and updated
   # under the lock (ADVICE round 4)
   with _lock:
@@ -468,29 +516,45 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     state.layout, state.keep_k, state.capacity = lay, keep_k, cap
 
   state.k, state.pending = None, None
+  state.key = key
   if capturing:
     map_raster(capacity)
     return
 
-  def settle():
-    global host_syncs
+  def settle(at_entry=False):
+    global settles
     state.pending = None
+    state.k_peek = None
+    with _lock:
+      try:
+        _unsettled.remove(state)
+      except ValueError:
+        pass
     try:
-      k_total = _wait_for_k(k_np, k_event)
+      k_total = _wait_for_k(k_np, k_event, at_entry)
     finally:
       ring.release(slot)        # this frame's word may serve another frame from here on
-    host_syncs += 1
+    settles += 1
     if k_total < 0:
       raise OverflowError(f"{what}: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
                           "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-    if state.capacity == 0 or k_total > state.capacity:
+    overflowed = state.capacity == 0 or k_total > state.capacity
+    with _lock:
+      _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
+      _choose_mapper(key, k_total, desc.n)
+      _stable_frames[key] = 0 if overflowed else _stable_frames.get(key, 0) + 1
+    if overflowed and state.consumed:
+      # found too late: the backward of this frame ran on the empty lists of the overflowed forward
+      raise FrameOverflow(
+        f"{what}: a frame produced {k_total} tile overlaps but was enqueued with room for {state.capacity}, and its "
+        "backward pass had been enqueued before the host looked (frame.LAZY_SETTLE): that frame rendered the background "
+        "only and returned zero gradients.  The capacity has been raised for the next frame; set MS_STRICT=1 (or "
+        "frame.LAZY_SETTLE = False) to make every frame wait for its overlap total before it returns.")
+    if overflowed:
       if visibility is not None and k_total > 0:
         visibility.zero_()
       map_raster(_round_capacity(k_total * K_SLACK))
     state.k = k_total
-    with _lock:
-      _k_capacity[key] = max(_k_capacity.get(key, 0), _round_capacity(k_total * K_SLACK))
-      _choose_mapper(key, k_total, desc.n)
 
   state.capacity = 0
   if capacity > 0:
@@ -499,10 +563,31 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     except Exception:
       ring.release(slot)          # (an allocation failure here must not leave the frame's K word busy for ever)
       raise
+  state.pending, state.k_peek = settle, k_np
   if capacity == 0 or settle_now:
     settle()
   else:
-    state.pending = settle
+    with _lock:
+      _unsettled.append(state)
+
+
+def settle_all():
+  """Settle every eager frame the host has not looked at yet, oldest first (next-frame entry, graph capture, tests)."""
+  while True:
+    with _lock:
+      if not _unsettled:
+        return
+      st = _unsettled[0]
+    with _lock:
+      fn, st.pending = st.pending, None
+      if fn is None and _unsettled and _unsettled[0] is st:
+        _unsettled.popleft()     # (settled by somebody else in the meantime)
+    if fn is not None:
+      fn(True)                   # removes itself from the queue first thing
+
+
+def lazy_settle_allowed(key) -> bool:
+  return LAZY_SETTLE and not STRICT and _stable_frames.get(key, 0) >= LAZY_AFTER
 
 
 _captured_frames = []      # weak references to the FrameStates of frames captured into HIP graphs
@@ -652,7 +737,7 @@ class _FrameFunction(torch.autograd.Function):
     lib = _lib.load()
     pos, lsc, rot, alog, feat, Tcw, proj, image = ctx.saved_tensors
     state, opts = ctx.state, ctx.opts
-    state.settle()              # (already done by render_frame; a caller of the bare Function gets it here)
+    state.settle_if_known()     # (done by render_frame unless the frame settles lazily: then only if it costs no wait)
     desc, config = state.desc, opts.config
     n, f = pos.shape[0], ctx.f
     device, dtype = pos.device, pos.dtype
@@ -822,7 +907,7 @@ class _RasterizeFrameFunction(torch.autograd.Function):
     lib = _lib.load()
     p, feats, image = ctx.saved_tensors
     state, config = ctx.state, ctx.config
-    state.settle()
+    state.settle_if_known()
     need_points, _, need_features = ctx.needs_input_grad[:3]
     heuristic = ctx.heuristic if config.compute_point_heuristic else None
     if g_image is None or not (need_points or need_features or heuristic is not None):
@@ -865,7 +950,8 @@ def rasterize_frame(gaussians2d, depth, features, image_size, config: RasterConf
   state = FrameState()
   out = _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
                                       bool(use_depth16), state)
-  state.settle()
+  if not (out[0].requires_grad and state.key is not None and lazy_settle_allowed(state.key)):
+    state.settle()
   return out
 
 
@@ -882,6 +968,7 @@ class LazyPoints:
     global point_syncs
     state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh = self.args
     n = depth.shape[0]
+    state.settle()
     with torch.no_grad():
       mask = depth > 0
       v = int(mask.sum().item())
@@ -928,14 +1015,33 @@ def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, u
   rendering = Rendering(image=image, image_weight=alpha, depth_image=None, median_depth_image=median, points=points,
                         camera=camera_params, config=config)
   object.__setattr__(rendering, 'frame', state)
-  state.settle()             # the host's one look at the overlap total: last, behind everything it had to do anyway
+  # the host's look at the overlap total: last, behind everything it had to do anyway — or, for a frame that is about to
+  # be differentiated on a scene shape with a settled capacity, not before the next frame (LAZY_SETTLE)
+  if not (image.requires_grad and state.key is not None and lazy_settle_allowed(state.key)):
+    state.settle()
   return rendering
+
+
+def point_outputs(rendering) -> dict:
+  """The frame's per-gaussian outputs at FULL size (one row per input gaussian, culled ones zero), without the host read of
+  the visible count that ``rendering.points`` costs: ``visibility`` (n,), ``point_heuristic`` (n, 2), ``depth`` (n,) — what a
+  training loop hands to ``VisibilityAwareAdam.step(indexes=None, visibility=...)`` (dense mode) and accumulates for
+  densification."""
+  points = object.__getattribute__(rendering, 'points')
+  if hasattr(points, 'args'):
+    _, _, _, depth, _, visibility, heuristic, config, _ = points.args
+    return {"visibility": visibility if config.compute_visibility else None,
+            "point_heuristic": heuristic if config.compute_point_heuristic else None, "depth": depth}
+  n = rendering.frame.desc.n if hasattr(rendering, 'frame') else int(points.idx.max()) + 1
+  return {"visibility": points.full_visibility(n) if points._visibility is not None else None,
+          "point_heuristic": None, "depth": None}
 
 
 def frame_status(rendering) -> dict:
   """Host read of a frame's device-side counters: overlap total, capacity, overflow flag (synchronises)."""
   state = getattr(rendering, 'frame', None)
   assert state is not None, "frame_status: not a rendering of the frame executor"
+  state.settle()
   k, live, overflow = state.counters()[:3].tolist()
   if overflow and state.captured:
     state.overflowed = 0               # reported here; check_replays() need not raise for it again
@@ -969,6 +1075,7 @@ class FrameGraph:
         step()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    settle_all()                                 # (the warm-up frames may settle lazily)
     self.graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self.graph):
       self.result = step()

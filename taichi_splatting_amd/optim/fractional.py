@@ -6,6 +6,7 @@ moment update (``fractional_adam.py`` / ``fractional_laprop.py`` Taichi kernels)
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -190,6 +191,61 @@ def fused_update(group: Group, visible_weight: torch.Tensor, visible_indexes: to
              "fractional optimizer update")
 
 
+def _group_args(group: Group, indexes_count: Optional[int], basis: Optional[torch.Tensor], keep: list) -> '_lib.OptimGroupC':
+  """One ``ms_optim_group`` (include/mi355_splat.h); tensors made here are appended to ``keep`` so that they outlive the
+  launch."""
+  if group.type not in GROUP_TYPES:
+    raise ValueError(f"unknown group type {group.type}")
+  m, v = PointState(group.state).moments(group.param, per_point_second_moment=group.type != "scalar")
+  param, grad = group.param, group.grad
+  d = param.shape[1]
+  _lib.require_gpu(param, grad)
+  assert param.is_contiguous() and param.dtype == torch.float32, "fractional optimisers run in contiguous float32"
+  grad = grad.contiguous()
+  b = None
+  if group.type == "local_vector":
+    assert basis is not None, "basis is required for local_vector optimizer"
+    assert indexes_count is None or tuple(basis.shape) == (indexes_count, d, d), \
+      f"basis must be (M, {d}, {d}), got {tuple(basis.shape)}"
+    b = basis.detach().to(torch.float32).contiguous()
+  mask_lr = group.mask_lr.to(device=param.device, dtype=torch.float32).reshape(-1).contiguous() if group.mask_lr is not None else None
+  if mask_lr is not None:
+    assert mask_lr.shape[0] == d, f"mask_lr must have {d} entries"
+  point_lr = group.point_lr.to(torch.float32).contiguous() if group.point_lr is not None else None
+  keep.extend((grad, b, mask_lr, point_lr, m, v))
+  g = _lib.OptimGroupC(group_type=GROUP_TYPES[group.type], param=_lib.ptr(param), grad=_lib.ptr(grad), m=_lib.ptr(m), v=_lib.ptr(v),
+                       basis=_lib.ptr(b), mask_lr=_lib.ptr(mask_lr), point_lr=_lib.ptr(point_lr), d=d,
+                       bias_correction=int(group.bias_correction), lr=float(group.lr), beta1=float(group.betas[0]),
+                       beta2=float(group.betas[1]), eps=float(group.eps),
+                       clip=float(group.clip) if group.clip is not None else -1.0, reserved=0.0)
+  g.struct_size = ctypes.sizeof(_lib.OptimGroupC)
+  return g
+
+
+def fused_update_groups(groups, visible_weight: torch.Tensor, visible_indexes: Optional[torch.Tensor],
+                        total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None,
+                        grad_scale: Optional[torch.Tensor] = None):
+  """Every parameter group of a step in ONE launch (``ms_optim_step_groups``, csrc/optim.hip): what the reference loops
+  over on the host (optim/fractional.py:176-195).  ``visible_indexes`` None = dense mode: row i is point i and rows with
+  a negative weight are skipped (``ms_optim_visibility_weights`` marks invisible points that way)."""
+  groups = [g for g in groups if g.grad is not None]
+  if not groups:
+    return
+  lib = _lib.load()
+  _lib.require_gpu(visible_weight, total_weight, visible_indexes)
+  weight = visible_weight.to(torch.float32).contiguous()
+  indexes = None
+  if visible_indexes is not None:
+    indexes = visible_indexes.contiguous()
+    assert indexes.dtype == torch.int64
+  gs = grad_scale.to(torch.float32).contiguous() if grad_scale is not None else None
+  keep = []
+  count = weight.shape[0]
+  array = (_lib.OptimGroupC * len(groups))(*[_group_args(g, count, basis, keep) for g in groups])
+  _lib.check(lib.ms_optim_step_groups(kind, array, len(groups), _lib.ptr(indexes), _lib.ptr(weight), _lib.ptr(total_weight),
+                                      _lib.ptr(gs), count, _lib.current_stream(weight.device)), "fractional optimizer step")
+
+
 def saturate(x: torch.Tensor):
   return 1 - 1 / torch.exp(2 * x)
 
@@ -216,10 +272,8 @@ class FractionalOpt(torch.optim.Optimizer):
     total_weight[indexes] += weight
 
     for group in groups:
-      if group.grad is None:
-        continue
-      assert group.num_points == n, f"param shape {group.num_points} != {n}"
-      fused_update(group, weight, indexes, total_weight, self.kind, basis)
+      assert group.grad is None or group.num_points == n, f"param shape {group.num_points} != {n}"
+    fused_update_groups(groups, weight, indexes, total_weight, self.kind, basis)
 
 
 class FractionalAdam(FractionalOpt):

@@ -8,7 +8,9 @@ from typing import Optional
 
 import torch
 
-from .fractional import ADAM, LAPROP, PointState, fused_update, make_group, saturate, weighted_step  # noqa: F401
+from .. import _lib
+from .fractional import (ADAM, LAPROP, PointState, fused_update, fused_update_groups, make_group, saturate,  # noqa: F401
+                         weighted_step)
 
 
 def _track_visibility(running: torch.Tensor, seen: torch.Tensor, indexes: torch.Tensor, beta: float,
@@ -78,25 +80,43 @@ class VisibilityOptimizer(torch.optim.Optimizer):
     super().__init__(params, defaults)
 
   @torch.no_grad()
-  def step(self, indexes: torch.Tensor, visibility: torch.Tensor, basis: Optional[torch.Tensor] = None):
-    assert visibility.shape == indexes.shape, f"shape mismatch {visibility.shape} != {indexes.shape}"
+  def step(self, indexes: Optional[torch.Tensor], visibility: torch.Tensor, basis: Optional[torch.Tensor] = None,
+           visible_threshold: float = 1e-8):
+    """Reference ``step(indexes, visibility, basis)`` (optim/visibility_aware.py:78-104): two launches — the step weights
+    (running visibility, total weight, gradient scale: ``ms_optim_visibility_weights``) and all parameter groups
+    (``ms_optim_step_groups``).
+
+    ``indexes=None`` is this library's DENSE mode: ``visibility`` then holds one value per point, and the points with
+    ``visibility <= visible_threshold`` are skipped on the device — same update as
+    ``visible = (visibility > 1e-8).nonzero().squeeze(1); step(visible, visibility[visible])`` of the reference's
+    training loop (examples/fit_image_gaussians.py:118-125) without its host synchronisation.  (``basis`` rows are
+    per point in that mode.)"""
     groups = [make_group(group, self.state) for group in self.param_groups]
     n = groups[0].num_points
+    if indexes is not None:
+      assert visibility.shape == indexes.shape, f"shape mismatch {visibility.shape} != {indexes.shape}"
+      assert indexes.dtype == torch.int64
+      indexes = indexes.contiguous()
+    else:
+      assert visibility.shape == (n,), f"dense mode: one visibility per point expected, got {tuple(visibility.shape)}"
 
     shared = PointState(groups[0].state)
     total_weight = shared.per_point('total_weight', n, visibility.device)
     running_vis = shared.per_point('running_vis', n, visibility.device)
-
-    weight = _track_visibility(running_vis, visibility, indexes, self.vis_beta)
-    total_weight[indexes] += weight
-
-    grad_scale = 1.0 / (visibility + self.vis_smooth)
     for group in groups:
-      if group.grad is None:
-        continue
-      assert group.num_points == n, f"param shape {group.num_points} != {n}"
-      # gradients are normalised by the point's visibility (reference :95-104): fused as a row scale
-      fused_update(group, weight, indexes, total_weight, self.kind, basis, grad_scale=grad_scale)
+      assert group.grad is None or group.num_points == n, f"param shape {group.num_points} != {n}"
+
+    _lib.require_gpu(visibility, indexes)
+    vis = visibility.detach().to(torch.float32).contiguous()
+    count = vis.shape[0]
+    weight, grad_scale = torch.empty_like(vis), torch.empty_like(vis)
+    # gradients are normalised by the point's visibility (reference :95-104): a row scale inside the group kernel
+    _lib.check(_lib.load().ms_optim_visibility_weights(_lib.ptr(indexes), _lib.ptr(vis), count, float(self.vis_beta),
+                                                       float(self.vis_smooth), 1e-12, float(visible_threshold),
+                                                       _lib.ptr(running_vis), _lib.ptr(total_weight), _lib.ptr(weight),
+                                                       _lib.ptr(grad_scale), _lib.current_stream(vis.device)),
+               "visibility-aware step weights")
+    fused_update_groups(groups, weight, indexes, total_weight, self.kind, basis, grad_scale=grad_scale)
 
 
 class VisibilityAwareAdam(VisibilityOptimizer):

@@ -342,3 +342,100 @@ def test_backward_staging_cases_vs_oracle(per_tile):
   # and every splat got its gradient: none lost most of its own row
   own = (pg.grad.cpu().double() - gp_o).abs().max(dim=1).values / gp_o.abs().max(dim=1).values.clamp_min(1e-3 * float(gp_o.abs().max()))
   assert int((own > 0.5).sum()) == 0
+
+
+# ---- eager frames that look at their overlap total late (frame.LAZY_SETTLE) ----------------
+def _train_scene(n=30000, size=(320, 240), seed=3):
+  from taichi_splatting_amd.testing import random_3d_gaussians, random_camera
+  torch.manual_seed(seed)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  return g.replace(feature=torch.rand(n, 3)), cam
+
+
+def test_lazily_settled_frames_equal_settled_frames_and_do_not_wait():
+  """From the fourth frame of a scene shape on, a frame that will be differentiated is not settled before it returns:
+  its backward is enqueued without a look at the overlap total (frame.host_syncs stays put), the look happens at the
+  next frame's entry.  Images and gradients are bit for bit those of frames settled the round-5 way (MS_STRICT-like:
+  LAZY_SETTLE off) — the kernels and their launch order are the same, only the host's wait moved."""
+  from taichi_splatting_amd import render_gaussians
+  g, cam = _train_scene()
+  cfg = RasterConfig()
+  weight = torch.linspace(0.5, 1.5, 240 * 320 * 3, device=DEV).view(240, 320, 3)
+  results = {}
+  for lazy in (False, True):
+    frame.release_caches()
+    frame.LAZY_SETTLE = lazy
+    try:
+      outs, waits = [], []
+      for it in range(7):
+        gd, camd = g.to(DEV), cam.to(device=DEV)
+        gd.requires_grad_(True)
+        before = frame.host_syncs
+        r = render_gaussians(gd, camd, cfg, use_sh=False)
+        pending = r.frame.pending is not None
+        (r.image * weight).sum().backward()
+        waits.append((frame.host_syncs - before, pending))
+        outs.append((r.image.detach().clone(), gd.position.grad.clone(), gd.feature.grad.clone()))
+      torch.cuda.synchronize()
+      frame.settle_all()
+      results[lazy] = (outs, waits)
+    finally:
+      frame.LAZY_SETTLE = True
+      frame.release_caches()
+  strict_waits, lazy_waits = results[False][1], results[True][1]
+  assert all(w == (1, False) for w in strict_waits), strict_waits
+  # (a lazily settled frame of this small scene may find its total already written when its backward is enqueued and
+  # settle there, without waiting; what it never does is look before it returns)
+  assert lazy_waits[:3] == [(1, False)] * 3 and all(w[1] for w in lazy_waits[4:]), lazy_waits
+  for a, b in zip(results[False][0], results[True][0]):
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):                       # float atomics: arrival order
+      assert float((x - y).abs().max()) <= 2e-5 * float(x.abs().max())
+
+
+def test_an_overflow_found_late_is_raised_not_swallowed():
+  """A lazily settled frame whose overlap total exceeds the remembered capacity (the splats grew threefold between two
+  frames of one scene shape) has rendered the background and returned zero gradients by the time the host looks: the look
+  (here: the next frame's entry) raises FrameOverflow, the capacity is raised, and the frame after that is right again.
+  A frame rendered WITHOUT gradients is always settled before it returns and is re-run in place."""
+  from taichi_splatting_amd import render_gaussians
+  import math
+  g, cam = _train_scene(seed=4)
+  cfg = RasterConfig()
+  frame.release_caches()
+  try:
+    for it in range(5):                                     # the shape settles: capacity known, stable
+      gd = g.to(DEV).requires_grad_(True)
+      render_gaussians(gd, cam.to(device=DEV), cfg, use_sh=False).image.sum().backward()
+    big = g.replace(log_scaling=g.log_scaling + math.log(3.0))
+    gd = big.to(DEV).requires_grad_(True)
+    camd = cam.to(device=DEV)
+    torch.cuda._sleep(400_000_000)                          # the GPU is busy (~0.2 s), as it is a frame behind in a training loop:
+    r = render_gaussians(gd, camd, cfg, use_sh=False)       # the host enqueues forward AND backward before K exists
+    assert r.frame.pending is not None
+    r.image.sum().backward()                                # enqueued on the overflowed (empty) lists
+    assert r.frame.consumed
+    torch.cuda.synchronize()
+    with pytest.raises(frame.FrameOverflow, match="zero gradients"):
+      render_gaussians(big.to(DEV), cam.to(device=DEV), cfg, use_sh=False)
+    assert float(gd.position.grad.abs().max()) == 0.0       # what the message says
+    # the next frames of the shape have room, with or without gradients
+    with torch.no_grad():
+      want = render_gaussians(big.to(DEV), cam.to(device=DEV), cfg, use_sh=False).image
+    gd = big.to(DEV).requires_grad_(True)
+    r = render_gaussians(gd, cam.to(device=DEV), cfg, use_sh=False)
+    r.image.sum().backward()
+    frame.settle_all()
+    assert torch.equal(r.image.detach(), want) and float(gd.position.grad.abs().max()) > 0
+    assert float(want.max()) > 0.05
+    # no gradients: settled before it returns, re-run in place when it does not fit
+    frame.release_caches()
+    for it in range(5):
+      with torch.no_grad():
+        render_gaussians(g.to(DEV), cam.to(device=DEV), cfg, use_sh=False)
+    with torch.no_grad():
+      r = render_gaussians(big.to(DEV), cam.to(device=DEV), cfg, use_sh=False)
+    assert r.frame.pending is None and torch.equal(r.image, want)
+  finally:
+    frame.release_caches()

@@ -156,3 +156,128 @@ def test_optimizer_classes_end_to_end():
       else:
         opt.step(idx)
     assert float((p ** 2).sum()) < before
+
+
+FIVE_GROUPS = [('position', 'scalar', 3), ('log_scaling', 'vector', 3), ('rotation', 'scalar', 4), ('alpha_logit', 'scalar', 1),
+               ('feature', 'vector', 48), ('sh', 'scalar', 48), ('offset', 'local_vector', 3), ('wide', 'scalar', 12)]
+
+
+def _five_group_case(seed, n=3000, mcount=1700, unaligned=False):
+  torch.manual_seed(seed)
+  idx = torch.randperm(n)[:mcount].sort().values
+  weight = torch.rand(mcount) * 1.5 + 0.01
+  tw = torch.rand(n) * 5 + weight.max()
+  groups = {}
+  for name, kind, d in FIVE_GROUPS:
+    groups[name] = dict(type=kind, d=d, param=torch.randn(n, d), grad=torch.randn(n, d), m=torch.randn(n, d) * 0.1,
+                        v=(torch.rand(n, d) if kind == 'scalar' else torch.rand(n)) * 0.1)
+  q, _ = torch.linalg.qr(torch.randn(mcount, 3, 3))
+  basis = q * (torch.rand(mcount, 1, 3) + 0.3)
+  return idx, weight, tw, groups, basis
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', [0, 1])
+@pytest.mark.parametrize('dense', [False, True])
+def test_all_groups_in_one_launch_match_the_oracle(kind, dense):
+  """ms_optim_step_groups: eight groups (rows of 3 / 3 / 4 / 1 / 48 / 48 / 3 / 12 floats; scalar, vector and local_vector;
+  16-byte pieces where the row length allows) in one launch against the restated host logic, group by group — with a
+  sparse index list and in the dense mode (row i = point i, negative weights skip)."""
+  from taichi_splatting_amd.optim.fractional import Group, fused_update_groups
+  idx, weight, tw, groups, basis = _five_group_case(31 + kind)
+  n, mc = tw.shape[0], idx.shape[0]
+  grad_scale = torch.rand(mc) + 0.5
+  want = {}
+  for name, g in groups.items():
+    p_o, m_o, v_o = g['param'].clone(), g['m'].clone(), g['v'].clone()
+    oopt.group_update(kind, g['type'], p_o, g['grad'], m_o, v_o, idx, weight, tw, 0.02, (0.9, 0.99), 1e-16, True,
+                      grad_scale=grad_scale, basis=basis if g['type'] == 'local_vector' else None, clip=0.9)
+    want[name] = (p_o, m_o, v_o)
+  dev = 'cuda:0'
+  if dense:
+    w_full, gs_full, basis_full = torch.full((n,), -1.0), torch.zeros(n), torch.zeros(n, 3, 3)
+    w_full[idx], gs_full[idx], basis_full[idx] = weight, grad_scale, basis
+    args = (w_full.to(dev), None, tw.to(dev))
+    extra = dict(basis=basis_full.to(dev), grad_scale=gs_full.to(dev))
+  else:
+    args = (weight.to(dev), idx.to(dev), tw.to(dev))
+    extra = dict(basis=basis.to(dev), grad_scale=grad_scale.to(dev))
+  states, objs = {}, []
+  for name, g in groups.items():
+    states[name] = {'v': g['m'].to(dev), 'm': g['v'].to(dev)}      # (the reference's naming quirk: 'v' is the first moment)
+    objs.append(Group(name=name, type=g['type'], param=g['param'].to(dev), grad=g['grad'].to(dev), state=states[name], lr=0.02,
+                      betas=(0.9, 0.99), eps=1e-16, bias_correction=True, clip=0.9, mask_lr=None, point_lr=None))
+  fused_update_groups(objs, args[0], args[1], args[2], kind, **extra)
+  untouched = torch.ones(n, dtype=torch.bool); untouched[idx] = False
+  for obj in objs:
+    p_o, m_o, v_o = want[obj.name]
+    assert torch.allclose(obj.param.cpu(), p_o, rtol=3e-4, atol=2e-6), (obj.name, (obj.param.cpu() - p_o).abs().max())
+    assert torch.allclose(states[obj.name]['v'].cpu(), m_o, rtol=3e-4, atol=2e-6), obj.name
+    assert torch.allclose(states[obj.name]['m'].cpu(), v_o, rtol=3e-4, atol=2e-6), obj.name
+    assert torch.equal(obj.param.cpu()[untouched], groups[obj.name]['param'][untouched]), obj.name
+
+
+@pytest.mark.gpu
+def test_visibility_weights_kernel_matches_the_oracle_and_dense_mode_skips():
+  from taichi_splatting_amd import _lib
+  lib = _lib.load()
+  dev = 'cuda:0'
+  torch.manual_seed(3)
+  n = 5000
+  vis_full = torch.rand(n) * (torch.rand(n) > 0.4)                 # 40 % invisible
+  idx = (vis_full > 1e-8).nonzero().squeeze(1)
+  running, tw = torch.rand(n), torch.rand(n) * 3
+  r_o, tw_o = running.clone(), tw.clone()
+  w_o, gs_o = oopt.visibility_weights(r_o, vis_full[idx], idx, tw_o, 0.8, 0.1)
+  stream = _lib.current_stream(torch.device(dev))
+  # sparse
+  r_g, tw_g = running.to(dev), tw.to(dev)
+  w_g, gs_g = torch.empty(idx.shape[0], device=dev), torch.empty(idx.shape[0], device=dev)
+  _lib.check(lib.ms_optim_visibility_weights(idx.to(dev).data_ptr(), vis_full[idx].to(dev).data_ptr(), idx.shape[0], 0.8, 0.1,
+                                             1e-12, 1e-8, r_g.data_ptr(), tw_g.data_ptr(), w_g.data_ptr(), gs_g.data_ptr(), stream), "w")
+  for got, want in ((r_g, r_o), (tw_g, tw_o), (w_g, w_o), (gs_g, gs_o)):
+    assert torch.allclose(got.cpu(), want, rtol=2e-6, atol=1e-7), (got.cpu() - want).abs().max()
+  # dense: same state, weights at the visible rows, -1 elsewhere, invisible rows untouched
+  r_d, tw_d = running.to(dev), tw.to(dev)
+  w_d, gs_d = torch.empty(n, device=dev), torch.empty(n, device=dev)
+  _lib.check(lib.ms_optim_visibility_weights(None, vis_full.to(dev).data_ptr(), n, 0.8, 0.1, 1e-12, 1e-8, r_d.data_ptr(),
+                                             tw_d.data_ptr(), w_d.data_ptr(), gs_d.data_ptr(), stream), "w dense")
+  assert torch.equal(r_d, r_g) and torch.equal(tw_d, tw_g)
+  assert torch.equal(w_d.cpu()[idx], w_g.cpu())
+  hidden = torch.ones(n, dtype=torch.bool); hidden[idx] = False
+  assert bool((w_d.cpu()[hidden] == -1).all()) and torch.equal(r_d.cpu()[hidden], running[hidden])
+
+
+@pytest.mark.gpu
+def test_visibility_aware_dense_step_equals_the_indexed_step():
+  """``step(None, visibility_of_every_point)`` (no torch.nonzero, no host synchronisation) leaves parameters and
+  optimiser state bit for bit where ``step(visible, visibility[visible])`` of the reference's loop leaves them."""
+  from taichi_splatting_amd.optim import ParameterClass, VisibilityAwareAdam
+  dev = 'cuda:0'
+  torch.manual_seed(0)
+  n = 4000
+  base = dict(position=torch.randn(n, 3), log_scaling=torch.randn(n, 3), rotation=torch.randn(n, 4), alpha_logit=torch.randn(n, 1),
+              feature=torch.randn(n, 3, 16))
+  groups = dict(position=dict(lr=0.01), log_scaling=dict(lr=0.02, type='vector'), rotation=dict(lr=0.01), alpha_logit=dict(lr=0.05),
+                feature=dict(lr=0.02, type='vector'))
+  results = []
+  for dense in (False, True):
+    params = ParameterClass({k: v.clone().to(dev) for k, v in base.items()}, groups, optimizer=VisibilityAwareAdam, vis_beta=0.8,
+                            vis_smooth=0.1, betas=(0.9, 0.95))
+    torch.manual_seed(1)
+    for it in range(4):
+      params.zero_grad()
+      loss = sum((t ** 2).sum() * (i + 1) for i, t in enumerate(params.tensors.values()))
+      loss.backward()
+      vis = (torch.rand(n, device=dev) * (torch.rand(n, device=dev) > 0.3)).contiguous()
+      if dense:
+        params.step(indexes=None, visibility=vis)
+      else:
+        visible = (vis > 1e-8).nonzero().squeeze(1)
+        params.step(indexes=visible, visibility=vis[visible])
+    results.append(({k: v.detach().clone() for k, v in params.tensors.items()}, params.tensor_state))
+  (pa, sa), (pb, sb) = results
+  for k in pa:
+    assert torch.equal(pa[k], pb[k]), k
+    for key in sa[k]:
+      assert torch.equal(sa[k][key], sb[k][key]), (k, key)
