@@ -407,6 +407,10 @@ typedef struct ms_frame_inputs {
    * cost does not depend on how the overlaps are spread over the tiles, and sets split_long_runs
    * (taichi_splatting_amd/frame.py does). */
   int32_t* longest_run_host;
+  /* optional hipEvent_t: ms_frame_map_raster makes `stream` wait for it right before the raster forward — the first kernel
+   * of the frame that reads `colours` (projected_input frames).  A multi-GPU rank step records it behind the collective
+   * that delivers the colours, so the mapper overlaps that transfer.  NULL: no wait. */
+  void* colours_ready_event;
 } ms_frame_inputs;
 
 enum { MS_BACKWARD_ALL = 0, MS_BACKWARD_GAUSSIANS = 1, MS_BACKWARD_RASTER = 2 };
@@ -582,6 +586,17 @@ int ms_strip_route_pack_slots(const float* points7, const float* features, const
                               const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
                               int64_t bucket_capacity, int32_t* overflow_flag,
                               float* out_rows, int64_t* out_send_index, int32_t* out_slots, void* stream);
+/* the same with the colours in a buffer of their own (round 6: the forward exchange as TWO collectives, so that the
+ * receiving strip's mapper — which reads geometry only — runs while the colours are still on the links):
+ * out_geometry_rows (S, 9) = [packed 2D (7) | depth | global id bits], out_colour_rows (S, f); both zero-filled by the
+ * caller for fixed buckets.  ms_strip_unpack(rows9, m, 0, points7, NULL, depths, ids) splits the geometry rows; the
+ * colour rows ARE the (m, f) colour array the rasterizer reads (ms_frame_inputs.colours +
+ * ms_frame_inputs.colours_ready_event). */
+int ms_strip_route_pack_split(const float* points7, const float* features, const float* depths,
+                              const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                              const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                              int64_t bucket_capacity, int32_t* overflow_flag, float* out_geometry_rows,
+                              float* out_colour_rows, int64_t* out_send_index, int32_t* out_slots, void* stream);
 int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_points7, float* out_features,
                     float* out_depths, int64_t* out_ids, void* stream);
 int ms_strip_return_grads(const float* back_rows, const int64_t* send_index, const int32_t* route,

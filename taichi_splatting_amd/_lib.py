@@ -86,7 +86,7 @@ class FrameInputsC(_SizedStructure):
   """``ms_frame_inputs``"""
   _fields_ = [('struct_size', ctypes.c_uint32), ('reserved', ctypes.c_uint32)] + [(name, c_void_p) for name in (
     'position', 'log_scaling', 'rotation', 'alpha_logit', 'feature', 'T_camera_world', 'projection',
-    'points7', 'depth', 'colours', 'longest_run_host')]
+    'points7', 'depth', 'colours', 'longest_run_host', 'colours_ready_event')]
 
 
 class FrameGradsC(_SizedStructure):
@@ -145,6 +145,7 @@ SIGNATURES = {
   'ms_strip_unpack': (c_int, [c_void_p, c_int64, c_int] + [c_void_p] * 4 + [c_void_p]),
   'ms_strip_return_grads': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
   'ms_strip_route_pack_slots': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 3 + [c_int64] + [c_void_p] * 5),
+  'ms_strip_route_pack_split': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, c_int64] + [c_void_p] * 3 + [c_int64] + [c_void_p] * 6),
   'ms_strip_return_rows': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
   'ms_fractional_update': (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_raster_fwd': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),

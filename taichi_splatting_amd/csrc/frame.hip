@@ -393,6 +393,8 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   SplitScratch split{};
   const bool cut = frame_uses_split(desc) && keep_k != nullptr;
   if (cut) split = split_scratch_carve(kk + L.split_scratch, d.k_capacity, d.raster.tile_size, frame_split_params(desc));
+  // the colours of a projected-input frame may still be arriving (a rank step's second forward collective)
+  if (in->colours_ready_event) MS_CHECK_HIP(hipStreamWaitEvent(s, (hipEvent_t)in->colours_ready_event, 0));
   return raster_fwd_launch(points7, colours, frame_uses_rows(desc) ? (const float*)(kn + L.splat_rows) : nullptr, ranges, o2p,
                            d.image_w, d.image_h, d.f, &d.raster, out_image, out_alpha, out_visibility, g.row_begin, g.row_end,
                            d.dtype, stream, cut ? &split : nullptr, in->longest_run_host);

@@ -187,7 +187,7 @@ constexpr float EXP2_BASIS_SCALE = 0.84932180028801904272f;   // sqrt(0.5 * log2
 // ~16 / sigma, so the rounding of the expanded form stays ~1e-6 in X.
 template <bool FWD_FORM = false>
 __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshold, float4* rec, float4* cull,
-                                              float origin_x = 0.0f, float origin_y = 0.0f) {
+                                              float origin_x = 0.0f, float origin_y = 0.0f, float log2_alpha_bias = 0.0f) {
   const float basis_scale = FWD_FORM ? EXP2_BASIS_SCALE : 1.0f;
   const float mx = r.g[0], my = r.g[1], ax = r.g[2], ay = r.g[3], sx = r.g[4], sy = r.g[5], alpha = r.g[6];
   const float isx = rcp_newton(sx), isy = rcp_newton(sy);
@@ -198,7 +198,8 @@ __device__ __forceinline__ void write_records(const Raw& r, float alpha_threshol
   } else {
     rec[0] = make_float4(mx, my, A, B);
   }
-  rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? -fast_log2(alpha) : alpha, r.f[0]);
+  // (FWD_FORM, log2_alpha_bias = log2(clamp_max_alpha): the exponential then yields alpha g / clamp_max, raster_fast.hip)
+  rec[1] = make_float4(C * basis_scale, D * basis_scale, FWD_FORM ? log2_alpha_bias - fast_log2(alpha) : alpha, r.f[0]);
   // (the forward reads 40 of the record's 48 bytes; it keeps its spent-wave flags in the last word of the first records,
   // so its stagers leave words 10 and 11 alone)
   if (FWD_FORM) *reinterpret_cast<float2*>(&rec[2]) = make_float2(r.f[1], r.f[2]);

@@ -19,6 +19,21 @@
 #ifndef MS_ABLATE
 #define MS_ABLATE 0
 #endif
+// Forward variants (round 6, tools/build_variant.sh; profiles/r06_raster_fwd_phase_split.txt):
+//   MS_FWD_PHASES      every wave adds up the shader cycles it spends per phase (ms_debug_fwd_phases, tools/rbench.py)
+//   MS_FWD_CLAMP_FOLD  the clamp of alpha to clamp_max_alpha as the free `clamp` output modifier of v_exp_f32: the
+//                      exponent carries + log2(clamp_max), the pixel state is T' = clamp_max T (w = a' T', T' -= clamp_max w)
+//   MS_FWD_SKIP_EMPTY  a hit none of whose 64 pixels passes the blend gate (the cull is conservative) leaves before
+//                      the colour read and the blend arithmetic
+#ifndef MS_FWD_PHASES
+#define MS_FWD_PHASES 0
+#endif
+#ifndef MS_FWD_CLAMP_FOLD
+#define MS_FWD_CLAMP_FOLD 1
+#endif
+#ifndef MS_FWD_SKIP_EMPTY
+#define MS_FWD_SKIP_EMPTY 0
+#endif
 // Hit-loop flavour (both measured on config D): the forward walks the hit mask with the record of the next hit
 // requested one iteration ahead; the backward body is long enough for the other waves of the SIMD to hide the
 // LDS latency and uses the leaner walk (one s_ff1 + one bit clear + one v_readlane per hit).
@@ -32,9 +47,27 @@ namespace ms {
 // (forward.py:126-131): one 6-step DPP sum per (patch, splat) hit with a contribution, summed over the
 // tile's patches in LDS (single-lane ds_add_f32) and committed with ONE global atomic per (tile, splat) —
 // the pass is bound by the global atomic rate, so the count is what matters.
+#if MS_FWD_PHASES
+// 0 barrier at the top of a batch (flags)   1 staging (records + the next gathers issued)   2 barrier after staging
+// 3 cull (LDS reads, test, ballot)   4 hit walk   5 visibility flush   6 epilogue   7 start .. first batch   8 whole wave
+// 9 hits   10 batches   11 waves
+__device__ unsigned long long* g_fwd_phase_rows = nullptr;
+#define MS_FPH(i) do { const uint64_t ph_now = __builtin_readcyclecounter(); ph_acc[i] += (uint32_t)(ph_now - ph_last); ph_last = ph_now; } while (0)
+#else
+#define MS_FPH(i) do {} while (0)
+#endif
 constexpr float FWD_SPENT_T = 1.3552527e-20f;   // 2^-66: transmittance below which the rest of a tile's list cannot change a pixel
 constexpr unsigned FWD_XCD_CHUNK = 8;      // tiles per XCD run (xcd_tile, raster_common.h)
 constexpr unsigned BWD_XCD_CHUNK = 8;      // pixel-per-lane backward: 3.12 -> 3.08 ms at tile 32, 2.84 -> 2.79 at tile 16
+
+#if MS_FWD_CLAMP_FOLD
+// exp2 of the biased exponent = alpha g / clamp_max; clamp(., 0, 1) is the v_exp_f32's own output modifier (no v_med3)
+#define FWD_ALPHA_BIAS (__builtin_amdgcn_logf(rp.clamp_max_alpha))
+__device__ __forceinline__ float fwd_alpha(float e, float) { return __builtin_amdgcn_fmed3f(e, 0.0f, 1.0f); }
+#else
+#define FWD_ALPHA_BIAS 0.0f
+__device__ __forceinline__ float fwd_alpha(float e, float clamp_max_alpha) { return clamp_alpha(e, clamp_max_alpha); }
+#endif
 
 template <int TS, bool VIS, bool ROWS, bool SEGS = false>   // ROWS: `points` is a splat-row table (common.h), `feats` unused;
 __global__ void __launch_bounds__(TS * TS)                  // SEGS: one workgroup per SEGMENT of a long tile run (raster_common.h)
@@ -48,6 +81,11 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   __shared__ float4 s_cull[BATCH * 2];
   __shared__ int32_t s_id[VIS ? BATCH : 1];
   __shared__ float s_vis[VIS ? BATCH : 1];
+#if MS_FWD_PHASES
+  const uint64_t ph_start = __builtin_readcyclecounter();
+  uint64_t ph_last = ph_start;
+  uint32_t ph_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
   int tile_id, start, end;
   if constexpr (SEGS) {
@@ -80,10 +118,17 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
   const float pxr = px - origin_x, pyr = py - origin_y;
 
   float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-  float T = in_bounds ? 1.0f : 0.0f;     // transmittance = 1 - accumulated weight
+  // transmittance = 1 - accumulated weight, carried as T' = TSCALE T (MS_FWD_CLAMP_FOLD: TSCALE = clamp_max_alpha)
+#if MS_FWD_CLAMP_FOLD
+  const float TSCALE = rp.clamp_max_alpha, GATE = rp.alpha_threshold / rp.clamp_max_alpha;
+#else
+  const float TSCALE = 1.0f, GATE = rp.alpha_threshold;
+#endif
+  float T = in_bounds ? TSCALE : 0.0f;
   // SEGS + VIS = the SECOND walk of a segment, behind the composition pass: it starts from the true transmittance at
   // the segment's start (what the composition left in the state) and exists for the visibility sums only
-  if constexpr (SEGS && VIS) T = rp.split_state[(int64_t)blockIdx.x * (TS * TS) + threadIdx.x].w;
+  if constexpr (SEGS && VIS) T = TSCALE * rp.split_state[(int64_t)blockIdx.x * (TS * TS) + threadIdx.x].w;
+  const float SPENT = FWD_SPENT_T * TSCALE;
 
   const int t = threadIdx.x;
 
@@ -111,21 +156,29 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
     // stores 40 of a record's 48 bytes): an LDS array of their own cost the kernel its eighth workgroup per CU (20 496
     // bytes instead of 20 480) and, with this compiler, 21 VGPRs (65 instead of 44-46) — the forward of config D ran
     // 0.56-0.59 ms instead of 0.52-0.54 for most of round 5 (tests/test_kernel_budgets.py holds it now).
-    const bool wave_spent = __ballot(T >= FWD_SPENT_T) == 0;
+    if (begin == start) MS_FPH(7);
+    const bool wave_spent = __ballot(T >= SPENT) == 0;
     if (lane == 0) reinterpret_cast<int*>(&s_rec[wave * 3 + 2])[3] = wave_spent ? 1 : 0;
     __syncthreads();                       // previous batch fully consumed; flags posted
     if (__ballot(reinterpret_cast<const int*>(&s_rec[(lane % (TS * TS / 64)) * 3 + 2])[3] != 0) == ~0ull) break;
+    MS_FPH(0);
     if (VIS && stager) {
       if (begin > start && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);   // previous batch
       s_vis[t] = 0.0f;
     }
+    MS_FPH(5);
     if (stager && begin + t < end) {
-      write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2], origin_x, origin_y);
+      write_records<true>(raw, rp.alpha_threshold, &s_rec[t * 3], &s_cull[t * 2], origin_x, origin_y, FWD_ALPHA_BIAS);
       if (VIS) s_id[t] = raw.id;
     }
     if (stager && begin + BATCH + t < end) raw = load_raw<ROWS>(points, feats, next_id);
     if (stager && begin + 2 * BATCH + t < end) next_id = o2p[begin + 2 * BATCH + t];
+    MS_FPH(1);
     __syncthreads();
+    MS_FPH(2);
+#if MS_FWD_PHASES
+    ph_acc[10] += 1;
+#endif
     if (wave_spent) continue;
 
     for (int r = 0; r < count; r += 64) {
@@ -133,7 +186,11 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
       bool hit = false;
       if (j < count) hit = patch_hit(s_cull[j * 2], s_cull[j * 2 + 1], rcx, rcy);
       unsigned long long m = __ballot(hit);
+      MS_FPH(3);
       if (m == 0) continue;
+#if MS_FWD_PHASES
+      ph_acc[9] += (uint32_t)__popcll(m);
+#endif
       if constexpr (VIS) {
         // visibility = per-splat sum of the blend weights (forward.py:126-131): the hits are taken four at a time
         // and ONE transposing reduction (wave_reduce4, 17 VALU) yields the four sums — 6 DPP adds + a ballot per hit
@@ -151,9 +208,9 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
               const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
               const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
               const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
-              const float a = clamp_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
-              const float w = a > rp.alpha_threshold ? a * T : 0.0f;
-              T -= w;
+              const float a = fwd_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
+              const float w = a > GATE ? a * T : 0.0f;
+              T = __builtin_fmaf(-TSCALE, w, T);
               c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
               wq[u] = w;
             }
@@ -173,26 +230,47 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
         // the forward uses 40 of the record's 48 bytes: the third read is 64 bits
         const float4 q0 = s_rec[(r + b) * 3 + 0], q1 = s_rec[(r + b) * 3 + 1];
+#if !MS_FWD_SKIP_EMPTY
         const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
+#endif
         // (X, Y) = basis * (pixel - mean), expanded around the tile centre (write_records<true>)
         const float X = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
         const float Y = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
-        // alpha * g in one exponential: A..D pre-scaled, q1.z = -log2(alpha) (write_records<true>)
-        const float a = clamp_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
+        // alpha * g in one exponential: A..D pre-scaled, q1.z = -log2(alpha) [+ log2(clamp_max)] (write_records<true>)
+        const float a = fwd_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y, Y, __builtin_fmaf(X, X, q1.z))), rp.clamp_max_alpha);
         // (the gate as arithmetic — clamp((E0 - e) 2^40, 0, 1) folded into an FMA, then a multiply — was measured in
         // round 4: 0.545 -> 0.560 ms on the same box; the compare + select stays)
-        const float w = a > rp.alpha_threshold ? a * T : 0.0f;
-        T -= w;
+        const bool pass = a > GATE;
+#if MS_FWD_SKIP_EMPTY
+        if (__ballot(pass) == 0) continue;
+        const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b) * 3 + 2]);
+#endif
+        const float w = pass ? a * T : 0.0f;
+        T = __builtin_fmaf(-TSCALE, w, T);
         c0 += q1.w * w; c1 += q2.x * w; c2 += q2.y * w;
       }
+      MS_FPH(4);
     }
   }
+  MS_FPH(6);
 
   if (VIS && end > start) {                // last batch
     __syncthreads();
     if (stager && s_vis[t] != 0.0f) atomic_add_noret(visibility + s_id[t], s_vis[t]);
   }
 
+#if MS_FWD_CLAMP_FOLD
+  T = T / TSCALE;                          // back to the transmittance itself (correctly rounded division, once per pixel)
+#endif
+#if MS_FWD_PHASES
+  if (g_fwd_phase_rows && lane == 0) {
+    unsigned long long* row = g_fwd_phase_rows + ((size_t)blockIdx.x * (TS * TS / 64) + wave) * 12;
+    const uint64_t now = __builtin_readcyclecounter();
+    ph_acc[6] += (uint32_t)(now - ph_last);
+    for (int i = 0; i < 8; ++i) row[i] = ph_acc[i];
+    row[8] = now - ph_start; row[9] = ph_acc[9]; row[10] = ph_acc[10]; row[11] = 1;
+  }
+#endif
   if constexpr (SEGS) {
     // (C_s, P_s) of this segment for the pixel; out-of-image pixels carry T = 0 throughout
     if constexpr (!VIS) rp.split_state[(int64_t)blockIdx.x * (TS * TS) + t] = make_float4(c0, c1, c2, T);
@@ -423,6 +501,15 @@ raster_bwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
 }  // namespace ms
 
 using namespace ms;
+
+#if MS_FWD_PHASES
+// rows: device buffer of (waves of the launch) x 12 uint64 the next launches fill (NULL: stop recording)
+extern "C" int ms_debug_fwd_phases(unsigned long long* rows, int unused) {
+  (void)unused;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase_rows), &rows, sizeof(rows));
+  return 0;
+}
+#endif
 
 static FastParams make_fast_params(int w, int h, const ms_raster_config* cfg, int row_begin, int num_tiles) {
   FastParams rp{};

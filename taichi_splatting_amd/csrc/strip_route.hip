@@ -107,7 +107,8 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
                   const int64_t* __restrict__ ids, int f, int v, int world, int nblocks, int64_t index_offset,
                   const int32_t* __restrict__ route, const int32_t* __restrict__ block_offsets,
                   const int64_t* __restrict__ send_counts, int64_t bucket_capacity, int32_t* __restrict__ overflow,
-                  float* __restrict__ rows, int64_t* __restrict__ send_index, int32_t* __restrict__ slots) {
+                  float* __restrict__ rows, int64_t* __restrict__ send_index, int32_t* __restrict__ slots,
+                  float* __restrict__ colour_rows) {
   constexpr int WAVES = ROUTE_BLOCK / 64;
   __shared__ int s_wave_count[WAVES][ROUTE_MAX_WORLD];
   __shared__ int64_t s_bucket_start[ROUTE_MAX_WORLD];
@@ -131,7 +132,8 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
     if (lane == 0) s_wave_count[wave][d] = __popcll(m);
   }
   __syncthreads();
-  const int width = 9 + f;
+  // colour_rows != NULL: the colours travel in a buffer (and a collective) of their own — rows = [packed 2D | depth | id]
+  const int width = colour_rows ? 9 : 9 + f;
   float g[7];
   float depth = 0.f;
   int id_bits = 0;
@@ -158,9 +160,15 @@ route_pack_kernel(const float* __restrict__ points7, const float* __restrict__ f
     float* row = rows + slot * width;
 #pragma unroll
     for (int k = 0; k < 7; ++k) row[k] = g[k];
-    for (int k = 0; k < f; ++k) row[7 + k] = feats[(int64_t)i * f + k];
-    row[7 + f] = depth;
-    row[8 + f] = __int_as_float(id_bits);
+    if (colour_rows) {
+      for (int k = 0; k < f; ++k) colour_rows[slot * f + k] = feats[(int64_t)i * f + k];
+      row[7] = depth;
+      row[8] = __int_as_float(id_bits);
+    } else {
+      for (int k = 0; k < f; ++k) row[7 + k] = feats[(int64_t)i * f + k];
+      row[7 + f] = depth;
+      row[8 + f] = __int_as_float(id_bits);
+    }
     send_index[slot] = i;
   }
 }
@@ -277,11 +285,10 @@ extern "C" int ms_strip_route_count(const float* points7, const float* depth, in
   return 0;
 }
 
-extern "C" int ms_strip_route_pack_slots(const float* points7, const float* features, const float* depths,
-                                         const int64_t* ids, int f, int v, int world, int64_t index_offset,
-                                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
-                                         int64_t bucket_capacity, int32_t* overflow_flag,
-                                         float* out_rows, int64_t* out_send_index, int32_t* out_slots, void* stream) {
+static int route_pack_launch(const float* points7, const float* features, const float* depths, const int64_t* ids, int f,
+                             int v, int world, int64_t index_offset, const int32_t* route, const int32_t* block_offsets,
+                             const int64_t* send_counts, int64_t bucket_capacity, int32_t* overflow_flag, float* out_rows,
+                             int64_t* out_send_index, int32_t* out_slots, float* out_colour_rows, void* stream) {
   MS_CHECK_ARG(v >= 0 && f >= 0 && world >= 1 && world <= ROUTE_MAX_WORLD, "bad sizes");
   if (v == 0) return 0;
   MS_CHECK_ARG(points7 && depths && route && block_offsets && send_counts && (f == 0 || features), "null pointer");
@@ -290,9 +297,28 @@ extern "C" int ms_strip_route_pack_slots(const float* points7, const float* feat
   route_pack_kernel<<<nblocks, ROUTE_BLOCK, 0, (hipStream_t)stream>>>(points7, features, depths, ids, f, v, world,
                                                                        nblocks, index_offset, route, block_offsets,
                                                                        send_counts, bucket_capacity, overflow_flag,
-                                                                       out_rows, out_send_index, out_slots);
+                                                                       out_rows, out_send_index, out_slots, out_colour_rows);
   MS_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int ms_strip_route_pack_slots(const float* points7, const float* features, const float* depths,
+                                         const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                                         int64_t bucket_capacity, int32_t* overflow_flag,
+                                         float* out_rows, int64_t* out_send_index, int32_t* out_slots, void* stream) {
+  return route_pack_launch(points7, features, depths, ids, f, v, world, index_offset, route, block_offsets, send_counts,
+                           bucket_capacity, overflow_flag, out_rows, out_send_index, out_slots, nullptr, stream);
+}
+
+extern "C" int ms_strip_route_pack_split(const float* points7, const float* features, const float* depths,
+                                         const int64_t* ids, int f, int v, int world, int64_t index_offset,
+                                         const int32_t* route, const int32_t* block_offsets, const int64_t* send_counts,
+                                         int64_t bucket_capacity, int32_t* overflow_flag, float* out_geometry_rows,
+                                         float* out_colour_rows, int64_t* out_send_index, int32_t* out_slots, void* stream) {
+  MS_CHECK_ARG(out_colour_rows != nullptr && f >= 1, "ms_strip_route_pack_split: colour rows");
+  return route_pack_launch(points7, features, depths, ids, f, v, world, index_offset, route, block_offsets, send_counts,
+                           bucket_capacity, overflow_flag, out_geometry_rows, out_send_index, out_slots, out_colour_rows, stream);
 }
 
 extern "C" int ms_strip_route_pack(const float* points7, const float* features, const float* depths,
@@ -308,6 +334,7 @@ extern "C" int ms_strip_unpack(const float* rows, int64_t m, int f, float* out_p
                                float* out_depths, int64_t* out_ids, void* stream) {
   MS_CHECK_ARG(m >= 0 && f >= 0, "bad sizes");
   if (m == 0) return 0;
+  // (f = 0, out_features = NULL: the 9-float geometry rows of ms_strip_route_pack_split)
   MS_CHECK_ARG(rows && out_points7 && out_depths && out_ids && (f == 0 || out_features), "null pointer");
   strip_unpack_kernel<<<(unsigned)div_up(m, 256), 256, 0, (hipStream_t)stream>>>(rows, m, f, out_points7, out_features,
                                                                                    out_depths, out_ids);

@@ -48,6 +48,20 @@ def _exchange_all_to_all(recv: torch.Tensor, send: torch.Tensor, group):
     recv.copy_(send)
 
 
+def _exchange_all_to_all_async(recv: torch.Tensor, send: torch.Tensor, group):
+  """The same all-to-all started WITHOUT making the current stream wait for it: returns ``wait()``, which does.  RCCL
+  runs the collective on the process group's own stream, collectives of one group in issue order: two exchanges issued
+  back to back travel one after the other, and whoever waits for the first is not held up by the second."""
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    from . import distributed
+    if not (send.is_cuda and distributed.host_group(group)):
+      distributed.note_collective('all_to_all_single', recv, send)
+      work = dist.all_to_all_single(recv, send, group=group, async_op=True)
+      return work.wait
+  _exchange_all_to_all(recv, send, group)
+  return lambda: None
+
+
 class StageTimer:
   """HIP events at the stage boundaries of a rank step (recorded on the step's stream, read after a synchronise):
   makes an N > 1 bench line interpretable — compute, exchange and host time can be told apart."""
@@ -415,11 +429,24 @@ class ShardedStep(_RankStep):
   ``step(shard, camera, loss_fn)``: ``shard`` holds this rank's gaussians (``index_offset`` = global index of its
   first one); afterwards ``.grad`` of its leaf tensors is the complete gradient of the summed loss."""
 
-  def __init__(self, *args, index_offset: int = 0, exchange=None, **kw):
+  def __init__(self, *args, index_offset: int = 0, exchange=None, exchange_async=None, split_exchange: Optional[bool] = None, **kw):
     super().__init__(*args, **kw)
     self.index_offset = int(index_offset)
     self.bucket_capacity = 0
     self.exchange = exchange or (lambda recv, send: _exchange_all_to_all(recv, send, self.group))
+    # Forward exchange as TWO collectives (round 6): geometry rows [packed 2D | depth | id] (36 bytes) first, colour rows
+    # (4 f bytes) behind them.  The strip's mapper reads geometry only, so it runs while the colours are on the links; the
+    # raster forward waits for them through an event (ms_frame_inputs.colours_ready_event).  exchange_async(recv, send)
+    # starts a collective and returns wait(), which makes the CURRENT stream wait for it.  MS_SPLIT_EXCHANGE=0: one collective.
+    import os
+    self.split_exchange = (os.environ.get('MS_SPLIT_EXCHANGE', '1') not in ('', '0')) if split_exchange is None else bool(split_exchange)
+    if exchange is not None and exchange_async is None:
+      # a caller that substitutes the blocking exchange (emulation, tests) gets it for both collectives
+      def exchange_async(recv, send, _ex=exchange):
+        _ex(recv, send)
+        return lambda: None
+    self.exchange_async = exchange_async or (lambda recv, send: _exchange_all_to_all_async(recv, send, self.group))
+    self._side = {}
 
   def probe(self, shard: Gaussians3D, camera_params: CameraParams, use_sh: bool, slack: float = 1.15, exchange=None):
     """one synchronising dry run (a collective: every rank calls it): the largest per-destination bucket over all
@@ -486,38 +513,68 @@ class ShardedStep(_RankStep):
                                         route.data_ptr(), block_offsets.data_ptr(), send_counts.data_ptr(), stream),
                "sharded step (route)")
     m = world * cap
-    width = 9 + f
+    split = self.split_exchange and f >= 1
+    width = 9 if split else 9 + f
     send = torch.zeros((m, width), dtype=dtype, device=device)
+    send_col = torch.zeros((m, f), dtype=dtype, device=device) if split else None
     send_index = torch.full((m,), -1, dtype=torch.int64, device=device)
     # slots[i, c] = row of the send buffer that carries copy c of gaussian i: where its gradient comes back
     slots = torch.empty((max(n, 1), world), dtype=torch.int32, device=device)
-    if n > 0:
+    if n > 0 and split:
+      _lib.check(lib.ms_strip_route_pack_split(points7.data_ptr(), colours.data_ptr(), depth.data_ptr(), None, f, n, world,
+                                               self.index_offset, route.data_ptr(), block_offsets.data_ptr(),
+                                               send_counts.data_ptr(), cap, self.flags.data_ptr(), send.data_ptr(),
+                                               send_col.data_ptr(), send_index.data_ptr(), slots.data_ptr(), stream),
+                 "sharded step (pack)")
+    elif n > 0:
       _lib.check(lib.ms_strip_route_pack_slots(points7.data_ptr(), colours.data_ptr(), depth.data_ptr(), None, f, n, world,
                                                self.index_offset, route.data_ptr(), block_offsets.data_ptr(),
                                                send_counts.data_ptr(), cap, self.flags.data_ptr(), send.data_ptr(),
                                                send_index.data_ptr(), slots.data_ptr(), stream), "sharded step (pack)")
     timer.mark('route_pack')
     recv = torch.empty_like(send)
-    self.exchange(recv, send)
-    timer.mark('exchange_forward')
-
     g2 = torch.empty((m, 7), dtype=dtype, device=device)
     f2 = torch.empty((m, f), dtype=dtype, device=device)
     d2 = torch.empty((m,), dtype=dtype, device=device)
     ids = torch.empty((m,), dtype=torch.int64, device=device)
-    _lib.check(lib.ms_strip_unpack(recv.data_ptr(), m, f, g2.data_ptr(), f2.data_ptr(), d2.data_ptr(), ids.data_ptr(), stream),
-               "sharded step (unpack)")
+    colours_ready = None
+    if split:
+      wait_geometry = self.exchange_async(recv, send)
+      wait_colours = self.exchange_async(f2, send_col)          # the received colour rows ARE the strip's colour array
+      wait_geometry()
+      timer.mark('exchange_forward')
+      # a side stream waits for the colours and records the event the raster forward waits for (fork / join: capturable)
+      main = torch.cuda.current_stream(device)
+      side = self._side.get(device.index)
+      if side is None:
+        side = self._side[device.index] = torch.cuda.Stream(device)
+      side.wait_stream(main)
+      with torch.cuda.stream(side):
+        wait_colours()
+        colours_ready = torch.cuda.Event()
+        colours_ready.record(side)
+      _lib.check(lib.ms_strip_unpack(recv.data_ptr(), m, 0, g2.data_ptr(), None, d2.data_ptr(), ids.data_ptr(), stream),
+                 "sharded step (unpack)")
+    else:
+      self.exchange(recv, send)
+      timer.mark('exchange_forward')
+      _lib.check(lib.ms_strip_unpack(recv.data_ptr(), m, f, g2.data_ptr(), f2.data_ptr(), d2.data_ptr(), ids.data_ptr(), stream),
+                 "sharded step (unpack)")
 
     # ---- this rank's strip from the received rows ------------------------------------------------------------------
     desc_b, _ = _desc(m, self.image_size, dtype, f, -1, self.config, self.depth_range, tile_rows=self.rows,
                       projected=True, capacity=self.k_capacity)
     in_b = _lib.FrameInputsC(points7=g2.data_ptr(), depth=d2.data_ptr(), colours=f2.data_ptr())
+    if colours_ready is not None:
+      in_b.colours_ready_event = int(colours_ready.cuda_event)
     lay_b, keep_b, keep_k, image, alpha = self._strip_forward(desc_b, in_b, device, dtype, f)
+    in_b.colours_ready_event = None          # (the backward calls read the same struct: the colours have long arrived)
     timer.mark('unpack_map_raster')
     loss, g_image = self._loss_and_image_grad(image, loss_fn, backward)
     timer.mark('loss')
     es = image.element_size()
-    self.comm_bytes = {"all_to_all_forward_bytes": m * width * es, "all_to_all_backward_bytes": m * (7 + f) * es if backward else 0,
+    self.comm_bytes = {"all_to_all_forward_bytes": m * (9 + f) * es, "all_to_all_backward_bytes": m * (7 + f) * es if backward else 0,
+                       "forward_collectives": 2 if split else 1,
                        "bucket_capacity_rows": cap, "off_chip_fraction": (world - 1) / world}
     if not backward:
       self._leave_step()

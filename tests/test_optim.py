@@ -233,14 +233,15 @@ def test_visibility_weights_kernel_matches_the_oracle_and_dense_mode_skips():
   # sparse
   r_g, tw_g = running.to(dev), tw.to(dev)
   w_g, gs_g = torch.empty(idx.shape[0], device=dev), torch.empty(idx.shape[0], device=dev)
-  _lib.check(lib.ms_optim_visibility_weights(idx.to(dev).data_ptr(), vis_full[idx].to(dev).data_ptr(), idx.shape[0], 0.8, 0.1,
+  idx_g, vis_g, vis_full_g = idx.to(dev), vis_full[idx].to(dev), vis_full.to(dev)      # (alive across the launches)
+  _lib.check(lib.ms_optim_visibility_weights(idx_g.data_ptr(), vis_g.data_ptr(), idx.shape[0], 0.8, 0.1,
                                              1e-12, 1e-8, r_g.data_ptr(), tw_g.data_ptr(), w_g.data_ptr(), gs_g.data_ptr(), stream), "w")
   for got, want in ((r_g, r_o), (tw_g, tw_o), (w_g, w_o), (gs_g, gs_o)):
     assert torch.allclose(got.cpu(), want, rtol=2e-6, atol=1e-7), (got.cpu() - want).abs().max()
   # dense: same state, weights at the visible rows, -1 elsewhere, invisible rows untouched
   r_d, tw_d = running.to(dev), tw.to(dev)
   w_d, gs_d = torch.empty(n, device=dev), torch.empty(n, device=dev)
-  _lib.check(lib.ms_optim_visibility_weights(None, vis_full.to(dev).data_ptr(), n, 0.8, 0.1, 1e-12, 1e-8, r_d.data_ptr(),
+  _lib.check(lib.ms_optim_visibility_weights(None, vis_full_g.data_ptr(), n, 0.8, 0.1, 1e-12, 1e-8, r_d.data_ptr(),
                                              tw_d.data_ptr(), w_d.data_ptr(), gs_d.data_ptr(), stream), "w dense")
   assert torch.equal(r_d, r_g) and torch.equal(tw_d, tw_g)
   assert torch.equal(w_d.cpu()[idx], w_g.cpu())

@@ -6,7 +6,7 @@ set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/taichi_splatting_amd/csrc
-out=$root/tools/abl/obj_$name
+out=$root/tools/variants/obj_$name
 mkdir -p "$out"
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-fast-math -fno-slp-vectorize"
 pids=()
@@ -19,6 +19,6 @@ case " $* " in *MS_WITH_ROWS_KERNEL*)      # the round-4 experiment, tools/exper
   pids+=($!);;
 esac
 for p in "${pids[@]}"; do wait "$p"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/abl/lib$name.so" "$out"/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/variants/lib$name.so" "$out"/*.o
 rm -rf "$out"
-echo "built tools/abl/lib$name.so"
+echo "built tools/variants/lib$name.so"

@@ -327,47 +327,102 @@ def main_static(args):
   for st in steps_:
     st.bucket_capacity = cap
     st.k_capacity = 1 << 26             # generous for the recording pass; fixed per rank below
-  # recording pass: every rank's send buffer
+  # recording pass: every rank's send buffers (geometry rows and colour rows: the split exchange)
+  rec_col = {}
   for r in range(W):
     def rec(recv, send, r=r):
-      if send.shape[1] == 12:
+      if send.shape[1] == 9:
         recorded[r] = send.clone()
+      elif send.shape[1] == 3:
+        rec_col[r] = send.clone()
       recv.copy_(send)
     steps_[r].exchange = rec
+    steps_[r].exchange_async = lambda recv, send, rec=rec: (rec(recv, send), (lambda: None))[1]
+    steps_[r].split_exchange = True
     with torch.no_grad():
       steps_[r].step(shards[r], cam, loss_fn, use_sh=True, backward=False)
+
+  # ---- modelled link time as MEASURED time: a collective = a spin kernel of the modelled duration (one thread: it takes
+  # no compute from the kernels beside it) + the device copy of its buffers, on a stream of its own like RCCL's.  The
+  # overlapped figure is then a measurement of what the GPU does while the "links" are busy, not arithmetic.
+  link = torch.cuda.Stream(dev)
+  a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda._sleep(1_000_000); torch.cuda.synchronize()
+  a.record(); torch.cuda._sleep(50_000_000); b.record(); torch.cuda.synchronize()
+  cycles_per_ms = 50_000_000 / a.elapsed_time(b)
+
+  def link_ms(nbytes_per_peer):
+    return nbytes_per_peer / (LINK_GBS * 1e9) * 1e3 + LAUNCH_US * 1e-3
+
   per_rank, per_rank_graph, stages = [], [], []
+  serial_ms, overlapped_ms, stages_overlapped = [], [], []
   for r in ([int(x) for x in args.ranks.split(',')] if args.ranks else range(W)):
     st, shard = steps_[r], shards[r]
-    recv_rows = torch.cat([recorded[s][r * cap:(r + 1) * cap] for s in range(W)]).contiguous()
+    recv_geo = torch.cat([recorded[s][r * cap:(r + 1) * cap] for s in range(W)]).contiguous()
+    recv_col = torch.cat([rec_col[s][r * cap:(r + 1) * cap] for s in range(W)]).contiguous()
+    recv_rows = torch.cat([recv_geo[:, :7], recv_col, recv_geo[:, 7:9]], dim=1).contiguous()
 
-    def ex(recv, send):
-      if send.shape[1] == 12:
-        recv.copy_(recv_rows)
-      else:
-        recv.copy_(send)
-    st.exchange = ex
-    with torch.no_grad():
-      st.step(shard, cam, loss_fn, use_sh=True, backward=False)
-    st.k_capacity = frame._round_capacity(int(st.check()['overlaps']) * 1.15)
+    def deliver(recv, send):
+      width = send.shape[1]
+      recv.copy_(recv_rows if width == 12 else recv_geo if width == 9 else recv_col if width == 3 else send)
+
+    def make_exchanges(charge_links):
+      def ex(recv, send):                       # blocking, on the step's stream: nothing overlaps it
+        if charge_links:
+          torch.cuda._sleep(int(link_ms(cap * send.shape[1] * 4) * cycles_per_ms))
+        deliver(recv, send)
+
+      def ex_async(recv, send):                 # on the link stream, collectives in issue order; wait() = stream wait
+        main = torch.cuda.current_stream()
+        link.wait_stream(main)
+        with torch.cuda.stream(link):
+          if charge_links:
+            torch.cuda._sleep(int(link_ms(cap * send.shape[1] * 4) * cycles_per_ms))
+          deliver(recv, send)
+          done = torch.cuda.Event()
+          done.record(link)
+        return lambda: torch.cuda.current_stream().wait_event(done)
+      return ex, ex_async
+
     leaves = (shard.position, shard.log_scaling, shard.rotation, shard.alpha_logit, shard.feature)
 
     def step():
       for t in leaves:
         t.grad = None
       st.step(shard, cam, loss_fn, use_sh=True)
+
+    def stage_table():
+      st.timer = sharded.StageTimer(True)
+      for _ in range(5):
+        step(); torch.cuda.synchronize(); st.timer.end_step()
+      table = st.timer.mean_ms()
+      st.timer = sharded.StageTimer(False)
+      return table
+
+    # (1) compute only, one forward collective (round 5's line): device copies, no link time
+    st.exchange, st.exchange_async = make_exchanges(False)
+    st.split_exchange = False
+    with torch.no_grad():
+      st.step(shard, cam, loss_fn, use_sh=True, backward=False)
+    st.k_capacity = frame._round_capacity(int(st.check()['overlaps']) * 1.15)
     per_rank.append(round(timed(step), 3))
-    st.timer = sharded.StageTimer(True)
-    for _ in range(5):
-      step(); torch.cuda.synchronize(); st.timer.end_step()
-    stages.append(st.timer.mean_ms())
-    st.timer = sharded.StageTimer(False)
+    stages.append(stage_table())
     graph = frame.FrameGraph(step, warmup=1)
     per_rank_graph.append(round(timed(graph.replay), 3))
     assert not st.check()['overlap_overflow'] and not st.check()['bucket_overflow']
     del graph
+    # (2) links charged, NOTHING overlapped: one forward collective, every collective blocks the step's stream
+    st.exchange, st.exchange_async = make_exchanges(True)
+    serial_ms.append(round(timed(step), 3))
+    # (3) links charged, what this round overlaps: geometry / colour collectives, the mapper runs beside the colours
+    st.split_exchange = True
+    overlapped_ms.append(round(timed(step), 3))
+    stages_overlapped.append(stage_table())
     for t in leaves:
       t.grad = None
+  f_ch = 3
+  geo_ms, col_ms = link_ms(cap * 9 * 4), link_ms(cap * f_ch * 4)
+  fwd_ms, bwd_ms = link_ms(cap * (9 + f_ch) * 4), link_ms(cap * (7 + f_ch) * 4)
   out = {"world": W, "n": args.n, "image": list(size), "step": "sharded.ShardedStep (sync-free, fixed buckets)",
          "single_gpu_ms": round(t_single, 3), "bounds": bounds, "bucket_capacity_rows": cap,
          "per_rank_ms_eager": per_rank, "per_rank_ms_graph": per_rank_graph,
@@ -375,11 +430,24 @@ def main_static(args):
          "compute_only_speedup_eager": round(t_single / max(per_rank), 2),
          "compute_only_speedup_graph": round(t_single / max(per_rank_graph), 2),
          "stage_ms_rank0": stages[0],
-         "note": "xGMI transfer time and RCCL latency not included (device copies stand in for the all-to-all)"}
-  f_ch = 3
+         "note": "compute_only_*: device copies stand in for the all-to-all (no xGMI time).  with_links: every collective ALSO "
+                 "runs a spin kernel of the modelled duration on the stream the collective would occupy, so the figures below "
+                 "are measured step times of this GPU under the stated link model, not sums"}
   out["exchanged_bytes_per_rank"] = {"forward": W * cap * (9 + f_ch) * 4, "backward": W * cap * (7 + f_ch) * 4,
                                      "off_chip_fraction": round((W - 1) / W, 3)}
   out["link_model"] = link_model(W, [cap * (9 + f_ch) * 4, cap * (7 + f_ch) * 4], max(per_rank_graph), t_single)
+  out["with_links"] = {
+    "assumes": f"{LINK_GBS:g} GB/s per link and direction, the {W - 1} links of a rank busy at once, {LAUNCH_US:g} us per collective",
+    "collective_ms": {"forward_one_collective": round(fwd_ms, 4), "forward_geometry": round(geo_ms, 4),
+                      "forward_colours": round(col_ms, 4), "backward": round(bwd_ms, 4)},
+    "per_rank_ms_serial": serial_ms, "per_rank_ms_overlapped": overlapped_ms,
+    "speedup_serial": round(t_single / max(serial_ms), 2),
+    "speedup_with_links": round(t_single / max(overlapped_ms), 2),
+    "overlap_built": "forward exchange as two collectives: the strip's mapper runs while the colour rows travel "
+                     "(ms_frame_inputs.colours_ready_event); the backward exchange is NOT overlapped",
+    "stage_ms_rank0_overlapped": stages_overlapped[0],
+    # what hiding the backward exchange behind the raster backward band by band could still gain, at most: all of it
+    "bound_if_backward_exchange_were_free": round(t_single / (max(overlapped_ms) - bwd_ms), 2)}
   emit(args, out)
 
 

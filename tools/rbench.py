@@ -18,6 +18,8 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
+FWD_PHASES = ['barrier_top', 'staging', 'barrier_staged', 'cull', 'hit_walk', 'visibility_flush', 'epilogue', 'before_first_batch']
+
 PHASES = ['barrier_top', 'staging', 'barrier_staged', 'cull', 'chunk_prologue', 'blend', 'chunk_epilogue', 'commit',
           'before_first_batch', 'wave_total', 'chunks', 'waves']
 
@@ -91,6 +93,30 @@ def main():
                                  image.data_ptr(), alpha.data_ptr(), None, 0, th, _lib.dtype_code(torch.float32), stream),
                "fwd")
   fwd()
+  out_fwd = {}
+  fwd_phase_fn = getattr(lib, 'ms_debug_fwd_phases', None)
+  if fwd_phase_fn is not None:
+    # -DMS_FWD_PHASES build: where a forward wave's cycles go (one row of 12 counters per wave)
+    fwd_phase_fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    blocks = (ranges2.shape[0] + 63) // 64 * 64                       # xcd_grid pads the launch to a multiple of 64 tiles
+    rows_f = torch.zeros((blocks * (cfg.tile_size * cfg.tile_size // 64), 12), dtype=torch.int64, device=dev)
+    fwd_phase_fn(ctypes.c_void_p(rows_f.data_ptr()), 0)
+    fwd()
+    torch.cuda.synchronize()
+    fwd_phase_fn(None, 0)
+    v = [int(x) for x in rows_f.sum(dim=0).tolist()]
+    total = max(v[8], 1)
+    out_fwd["fwd_phases_frac"] = {FWD_PHASES[i]: round(v[i] / total, 4) for i in range(8)}
+    out_fwd["fwd_phases_frac"]["unaccounted"] = round(1.0 - sum(v[:8]) / total, 4)
+    out_fwd["fwd_cycles_per_wave"] = round(total / max(v[11], 1))
+    out_fwd["fwd_hits"] = v[9]
+    out_fwd["fwd_batches"] = v[10]
+    out_fwd["fwd_cycles_per_hit_in_walk"] = round(v[4] / max(v[9], 1), 1)
+    out_fwd["fwd_cull_cycles_per_batch"] = round(v[3] / max(v[10], 1), 1)
+    out_fwd["fwd_staging_cycles_per_batch"] = round(v[1] / max(v[10], 1), 1)
+    out_fwd["fwd_barrier_cycles_per_batch"] = round((v[0] + v[2]) / max(v[10], 1), 1)
+    busy = rows_f[rows_f[:, 11] > 0]
+    out_fwd["fwd_wave_cycles_quantiles"] = [int(q) for q in busy[:, 8].double().quantile(torch.tensor([0.05, 0.5, 0.95, 1.0], dtype=torch.float64, device=dev)).tolist()]
   torch.manual_seed(1)
   grad_image = torch.rand_like(image) + 0.5
   mom = torch.zeros((n, _lib.MOMENT_ROW), device=dev)
@@ -123,6 +149,7 @@ def main():
   torch.cuda.synchronize()
   out = {"tag": args.tag or os.path.basename(os.environ.get('MS_SPLAT_LIB', 'default')), "scene": args.scene,
          "tile": args.tile, "V": n, "K": k}
+  out.update(out_fwd)
   if stats_fn is not None:
     stats_fn(ctypes.cast(stats, ctypes.c_void_p), 1)
     v = [int(x) for x in stats]
