@@ -120,15 +120,35 @@ __device__ __forceinline__ float group_sum(float x) {
   return x;
 }
 
+// -DMS_OPTIM_NT=1 (tools/build_variant.sh): the gradient rows — read once, never again — are loaded non-temporally
+#ifndef MS_OPTIM_NT
+#define MS_OPTIM_NT 0
+#endif
 template <int VEC> struct Piece;
 template <> struct Piece<1> {
   static __device__ __forceinline__ void load(const float* p, float* out) { out[0] = *p; }
+  static __device__ __forceinline__ void load_once(const float* p, float* out) {
+#if MS_OPTIM_NT
+    out[0] = __builtin_nontemporal_load(p);
+#else
+    out[0] = *p;
+#endif
+  }
   static __device__ __forceinline__ void store(float* p, const float* v) { *p = v[0]; }
 };
 template <> struct Piece<4> {
   static __device__ __forceinline__ void load(const float* p, float* out) {
     const float4 q = *reinterpret_cast<const float4*>(p);
     out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+  }
+  static __device__ __forceinline__ void load_once(const float* p, float* out) {
+#if MS_OPTIM_NT
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    const vec4 q = __builtin_nontemporal_load(reinterpret_cast<const vec4*>(p));
+    out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+#else
+    load(p, out);
+#endif
   }
   static __device__ __forceinline__ void store(float* p, const float* v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -160,7 +180,7 @@ __device__ __forceinline__ void update_point(const GroupArgs& a, const CommonArg
     const int j = (sub + k * LPP) * VEC;
     const bool ok = live && j < d;
     if (ok) {
-      Piece<VEC>::load(a.grad + row + j, g + k * VEC);
+      Piece<VEC>::load_once(a.grad + row + j, g + k * VEC);
       Piece<VEC>::load(a.m + row + j, mo + k * VEC);
       if (TYPE == 0) Piece<VEC>::load(a.v + row + j, vo + k * VEC);
       if (!a.out_step) Piece<VEC>::load(a.param + row + j, pa + k * VEC);
@@ -487,7 +507,9 @@ extern "C" int ms_optim_step_groups(int kind, const ms_optim_group* groups, int 
     const GroupArgs a{g.param, g.grad, g.m, g.v, g.basis, g.mask_lr, g.point_lr, g.d, g.lr, g.eps, g.clip, g.bias_correction,
                       (float)log2((double)g.beta1), (float)log2((double)g.beta2), nullptr};
     const int shape = pick_shape(g.group_type, a);
-    const bool fusable = shape != S_V1_L16_K4 && shape != S_V1_L16_K16 && shape != S_V4_L16_K4;
+    // MS_OPTIM_FUSED=0 (read once): one launch per group, for A/B measurements of the fused launch
+    static const bool allow_fused = [] { const char* e = getenv("MS_OPTIM_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fusable = allow_fused && shape != S_V1_L16_K4 && shape != S_V1_L16_K16 && shape != S_V4_L16_K4;
     if (!fusable) {                                  // rows wider than 64 floats (or 16 unaligned): a launch of their own
       const int rc2 = launch_update(kind, g.group_type, a, c, s);
       if (rc2) return rc2;

@@ -34,6 +34,10 @@
 #ifndef MS_FWD_SKIP_EMPTY
 #define MS_FWD_SKIP_EMPTY 0
 #endif
+//   MS_FWD_PAIR        the hit walk takes two hits per iteration (both records requested before either is used)
+#ifndef MS_FWD_PAIR
+#define MS_FWD_PAIR 1
+#endif
 // Hit-loop flavour (both measured on config D): the forward walks the hit mask with the record of the next hit
 // requested one iteration ahead; the backward body is long enough for the other waves of the SIMD to hide the
 // LDS latency and uses the leaner walk (one s_ff1 + one bit clear + one v_readlane per hit).
@@ -223,8 +227,35 @@ raster_fwd_f32x3_kernel(const float* __restrict__ points, const float* __restric
         }
         continue;
       }
-      // plain hit loop: one scalar bit scan + bit clear per hit (the compiler turns a hand-written prefetch of the
-      // next record into a dozen scalar instructions per hit and drops the prefetch itself)
+      // plain hit loop: one scalar bit scan + bit clear per hit (the compiler turns a hand-written prefetch of the next
+      // record into a dozen scalar instructions per hit and drops the prefetch itself).  Round 6: hits are taken TWO at
+      // a time — a wave alone needs ~190 cycles per hit (LDS round trip, then fourteen dependent VALU instructions)
+      // while its share of the SIMD's issue slots is ~40: with both records requested up front and the two alpha chains
+      // independent until the transmittance, the scheduler interleaves them (profiles/r06_raster_fwd_phase_split.txt)
+#if MS_FWD_PAIR
+      while (m & (m - 1)) {                                // at least two hits left
+        const int b0 = __builtin_ctzll(m);
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b0));
+        const int b1 = __builtin_ctzll(m);
+        asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b1));
+        const float4 p0 = s_rec[(r + b0) * 3 + 0], p1 = s_rec[(r + b0) * 3 + 1];
+        const float4 q0 = s_rec[(r + b1) * 3 + 0], q1 = s_rec[(r + b1) * 3 + 1];
+        const float2 p2 = *reinterpret_cast<const float2*>(&s_rec[(r + b0) * 3 + 2]);
+        const float2 q2 = *reinterpret_cast<const float2*>(&s_rec[(r + b1) * 3 + 2]);
+        const float X0 = __builtin_fmaf(pxr, p0.z, __builtin_fmaf(pyr, p0.w, -p0.x));
+        const float X1 = __builtin_fmaf(pxr, q0.z, __builtin_fmaf(pyr, q0.w, -q0.x));
+        const float Y0 = __builtin_fmaf(pxr, p1.x, __builtin_fmaf(pyr, p1.y, -p0.y));
+        const float Y1 = __builtin_fmaf(pxr, q1.x, __builtin_fmaf(pyr, q1.y, -q0.y));
+        const float a0 = fwd_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y0, Y0, __builtin_fmaf(X0, X0, p1.z))), rp.clamp_max_alpha);
+        const float a1 = fwd_alpha(__builtin_amdgcn_exp2f(-__builtin_fmaf(Y1, Y1, __builtin_fmaf(X1, X1, q1.z))), rp.clamp_max_alpha);
+        const float w0 = a0 > GATE ? a0 * T : 0.0f;
+        T = __builtin_fmaf(-TSCALE, w0, T);
+        c0 += p1.w * w0; c1 += p2.x * w0; c2 += p2.y * w0;
+        const float w1 = a1 > GATE ? a1 * T : 0.0f;
+        T = __builtin_fmaf(-TSCALE, w1, T);
+        c0 += q1.w * w1; c1 += q2.x * w1; c2 += q2.y * w1;
+      }
+#endif
       while (m != 0) {
         const int b = __builtin_ctzll(m);
         asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));

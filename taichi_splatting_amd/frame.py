@@ -472,12 +472,18 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
         _presort_sticky.add(key)
         _mapper_mode[key] = _lib.MAPPER_PRESORT
       inputs.longest_run_host = run_word[0].data_ptr()
-    # the same in every call of this frame; before the first frame of a shape only the key width is known
-    desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT if key[-1] is True else _lib.MAPPER_DIRECT)
+    # the same in every call of this frame.  The FIRST frame of a scene shape (nothing known about how its overlaps are
+    # spread) takes the sequence whose cost does not depend on that — the pre-sort, 0.1-0.2 ms dearer on a scene like
+    # config D — and carries the segment launches: a pile-up then costs its first frame what it costs every frame, not
+    # the 7 ms of ONE workgroup sorting a 244 000-entry run plus one workgroup rasterizing it (round 5's first frame of
+    # that shape: 11.1 ms against 1.67 steady; tools/sweep_scenes.py guards first <= 3 x steady).  The second frame
+    # runs what _choose_mapper settled on.
+    first_of_shape = key not in _mapper_mode
+    desc.mapper = _mapper_mode.get(key, _lib.MAPPER_PRESORT)
     # a shape that showed a run above LONG_RUN_LIMIT also has its long runs rasterized in segments (the raster forward
     # reports such runs through the same word on either mapper sequence)
     # (field value 1 = the default threshold, > 1 = the threshold itself; the library raises thresholds below 256)
-    split_on = SPLIT_LONG_RUNS and (SPLIT_ALWAYS or key in _presort_sticky)
+    split_on = SPLIT_LONG_RUNS and (SPLIT_ALWAYS or first_of_shape or key in _presort_sticky)
     desc.split_long_runs = (max(2, SPLIT_MIN_RUN) if SPLIT_MIN_RUN > 0 else 1) if split_on else 0
     desc.split_seg_len = SPLIT_SEG_LEN
   if capturing and capacity == 0:

@@ -439,3 +439,84 @@ def test_an_overflow_found_late_is_raised_not_swallowed():
     assert r.frame.pending is None and torch.equal(r.image, want)
   finally:
     frame.release_caches()
+
+
+# ---- scene shapes of the round-6 sweep (tools/sweep_scenes.py): half-culled, needle splats -------------------------
+def _shape_scene(kind, n, size, seed):
+  import math
+  from taichi_splatting_amd.testing import random_3d_gaussians, random_camera
+  torch.manual_seed(seed)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(n, cam, scale_factor=0.7 if kind == 'needle' else 1.0, alpha_range=(0.1, 0.9),
+                          margin=0.5 if kind == 'culled' else 0.0)
+  if kind == 'needle':
+    stretch = torch.zeros(n, 3)
+    stretch[torch.arange(n), torch.randint(0, 3, (n,))] = math.log(10.0)
+    g = g.replace(log_scaling=g.log_scaling + stretch)
+  return g.replace(feature=torch.rand(n, 3)), cam
+
+
+@pytest.mark.parametrize('kind', ['culled', 'needle'])
+@pytest.mark.parametrize('tile', [8, 16, 32])
+def test_new_sweep_shapes_lists_against_the_oracle(kind, tile):
+  """Half-culled scenes (56 % of the gaussians outside the image: the compaction's int64 index list, N-sized buffers with
+  V ~ N / 2 live rows) and needle splats (aspect ~10 at random orientations: the oriented-box test decides most tile
+  candidates): the tile lists of both mapper sequences are identical to the numpy oracle's (tile, depth bits, point
+  index) order, and the frame executor — which never compacts — renders the image of the modular operators bit for bit."""
+  from oracle import mapper as omap
+  from taichi_splatting_amd import render_gaussians
+  from taichi_splatting_amd.perspective.projection import project_to_image
+  from taichi_splatting_amd.rendering import ndc_depth
+  size = (400, 304)
+  n = 30000
+  g, cam = _shape_scene(kind, n, size, seed=tile + (50 if kind == 'needle' else 0))
+  cfg = cfg_for(tile)
+  gd, camd = g.to(DEV), cam.to(device=DEV)
+  with torch.no_grad():
+    g2d, depths, idx = project_to_image(gd, camd, cfg)
+  v = g2d.shape[0]
+  if kind == 'culled':
+    assert 0.3 * n < v < 0.7 * n and idx.dtype == torch.int64, v
+  else:
+    sig = g2d[:, 4:6]
+    assert float((sig.max(dim=1).values / sig.min(dim=1).values).median()) > 3.0        # needles on screen too
+  ndc = ndc_depth(depths, cam.near_plane, cam.far_plane)
+  want_o2p, want_ranges, _ = omap.map_to_tiles(g2d.cpu().numpy(), ndc.cpu().reshape(-1).numpy(), size, tile, cfg.alpha_threshold)
+  for method in ('direct', 'presort'):
+    o2p, ranges = map_to_tiles(g2d, ndc, size, cfg, method=method)
+    assert o2p.shape[0] == want_o2p.shape[0], (method, o2p.shape[0], want_o2p.shape[0])
+    assert torch.equal(ranges.view(-1, 2).cpu(), torch.from_numpy(want_ranges).view(-1, 2)), method
+    assert torch.equal(o2p.cpu(), torch.from_numpy(want_o2p)), method
+  # frame executor (gaussians stay in place, culled ones carry depth 0) against the modular operators on the compacted set
+  frame.release_caches()
+  try:
+    with torch.no_grad():
+      r = render_gaussians(gd, camd, cfg, use_sh=False)
+      o2p, ranges = map_to_tiles(g2d, ndc, size, cfg)
+      want = rasterize_with_tiles(g2d, gd.feature[idx], o2p, ranges.view(-1, 2), size, cfg)
+    assert torch.equal(r.image, want.image) and torch.equal(r.image_weight, want.image_weight)
+    assert int(frame.frame_status(r)['overlaps']) == want_o2p.shape[0]
+    assert torch.equal(r.points.idx, idx)
+  finally:
+    frame.release_caches()
+
+
+def test_first_frame_of_a_shape_maps_with_the_presort_and_carries_the_segments():
+  """The first frame of a scene shape knows nothing about how its overlaps are spread: it runs the sequence whose cost
+  does not depend on that (pre-sort) with the long-run segments switched on, the next frames what the shape settled on.
+  Same lists, same image either way."""
+  from taichi_splatting_amd import render_gaussians
+  g, cam = _shape_scene('plain', 30000, (320, 240), seed=9)
+  cfg = RasterConfig()
+  frame.release_caches()
+  try:
+    gd, camd = g.to(DEV), cam.to(device=DEV)
+    with torch.no_grad():
+      first = render_gaussians(gd, camd, cfg, use_sh=False)
+      second = render_gaussians(gd, camd, cfg, use_sh=False)
+    assert int(first.frame.desc.mapper) == _lib.MAPPER_PRESORT and int(first.frame.desc.split_long_runs) == 1
+    assert int(second.frame.desc.mapper) == _lib.MAPPER_DIRECT and int(second.frame.desc.split_long_runs) == 0
+    assert torch.equal(first.image, second.image)
+    assert torch.equal(first.frame.overlap_to_point()[:first.frame.k], second.frame.overlap_to_point()[:second.frame.k])
+  finally:
+    frame.release_caches()

@@ -211,12 +211,12 @@ def test_both_launch_sequences_give_the_same_lists_and_the_policy_switches():
       frame.release_caches()
       frame.PRESORT_ABOVE, frame.DIRECT_BELOW = above, below
       modes = []
-      for _ in range(2):                       # the first frame of a shape maps directly; the second as decided
+      for _ in range(2):                       # the first frame of a shape maps with the pre-sort; the second as decided
         state = frame.FrameState()
         frame._RasterizeFrameFunction.apply(p, depth, features, (192, 128), cfg, False, state)
         state.settle()
         modes.append(int(state.desc.mapper))
-      assert modes == [0, want_second]
+      assert modes == [1, want_second]
       k = int(state.counters()[0])
       results.append((state.overlap_to_point()[:k].clone(), state.tile_ranges().clone()))
     assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
@@ -240,6 +240,11 @@ def test_a_giant_run_moves_the_scene_shape_to_the_presort_sequence():
   assert int((want_ranges[..., 1] - want_ranges[..., 0]).max()) > frame.LONG_RUN_LIMIT
   frame.release_caches()
   try:
+    # a shape that had settled on the direct sequence (few overlaps per gaussian) and now piles up: the direct sequence's
+    # per-tile sort reports the run, the next frame maps with the pre-sort.  (The FIRST frame of an unknown shape maps with
+    # the pre-sort anyway since round 6.)
+    key = ('2d',) + frame._shape_key(torch.device(DEV), n, size, cfg, None, False)
+    frame._mapper_mode[key] = _lib_direct()
     modes = []
     for _ in range(3):
       state = frame.FrameState()
@@ -250,5 +255,19 @@ def test_a_giant_run_moves_the_scene_shape_to_the_presort_sequence():
       k = int(state.counters()[0])
       assert torch.equal(state.tile_ranges(), want_ranges) and torch.equal(state.overlap_to_point()[:k], want_o2p)
     assert modes == [0, 1, 1]
+    frame.release_caches()
+    modes = []
+    for _ in range(2):
+      state = frame.FrameState()
+      frame._RasterizeFrameFunction.apply(p, depth, features, size, cfg, False, state)
+      state.settle()
+      torch.cuda.synchronize()
+      modes.append((int(state.desc.mapper), int(state.desc.split_long_runs)))
+    assert modes == [(1, 1), (1, 1)] and key in frame._presort_sticky
   finally:
     frame.release_caches()
+
+
+def _lib_direct():
+  from taichi_splatting_amd import _lib
+  return _lib.MAPPER_DIRECT

@@ -9,7 +9,13 @@ whose cost per overlap exceeds GUARD x config D's.
            4096^2 (the reference's three resolutions, BENCHMARK.md:36-40);  a heavy-tailed mix (5 % of the splats at
            20 x scale);  a pile-up (every splat centred inside one 48 x 48 px window: tile runs of ~100 000 entries,
            which the raster kernels cut into segments: ms_raster_fwd_split / ms_raster_bwd_moments_split);
-           the reference's dense 2D component shape (benchmarks/bench_rasterizer.py:21-26)
+           the reference's dense 2D component shape (benchmarks/bench_rasterizer.py:21-26);
+           round 6 — what trained scenes look like and the bench scene does not: HALF-CULLED
+           scenes (random_3d_gaussians(margin=0.5): 56 % of the gaussians outside the image, V ~ N / 2), NEEDLE scenes (one
+           log-scale axis + ln 10: strongly anisotropic splats, the oriented-box cull levels), and a ZOOM path whose
+           overlaps per gaussian cross the direct / pre-sort crossover every few frames.
+  first    the FIRST frame of every shape (shape caches cold: capacity unknown, mapper sequence unknown, no long-run
+           record; allocator warm) beside the steady frame, guarded at FIRST_GUARD x
 
     python tools/sweep_scenes.py [--quick] [--out profiles/r05_scene_sweep.txt]
 """
@@ -26,6 +32,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 GUARD = 2.0
+FIRST_GUARD = 3.0
 
 
 def cuda_ms(fn, iters=5, warmup=2):
@@ -56,7 +63,12 @@ def make_scene(spec, dev):
   size = (spec['side'], spec['side'])
   cam = random_camera(image_size=size)
   n = spec['n']
-  g = random_3d_gaussians(n, cam, scale_factor=spec['scale'], alpha_range=spec['alpha'], margin=0.0)
+  g = random_3d_gaussians(n, cam, scale_factor=spec['scale'], alpha_range=spec['alpha'], margin=spec.get('margin', 0.0))
+  if spec['kind'] == 'needle':
+    # one axis ten times longer than the generator's: splats of aspect ~10 at random orientations
+    stretch = torch.zeros(n, 3)
+    stretch[torch.arange(n), torch.randint(0, 3, (n,))] = math.log(10.0)
+    g = g.replace(log_scaling=g.log_scaling + stretch)
   if spec['kind'] == 'heavy_tail':
     big = torch.rand(n) < 0.05
     g = g.replace(log_scaling=g.log_scaling + math.log(20.0) * big[:, None].float())
@@ -165,8 +177,18 @@ def measure(spec, dev):
       render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
     first = time.perf_counter()
     step(); torch.cuda.synchronize()
-    out['first_frame_ms'] = (time.perf_counter() - first) * 1e3
+    out['first_frame_wall_ms'] = (time.perf_counter() - first) * 1e3       # includes the allocator's hipMallocs
     out['frame_ms'] = cuda_ms(step, iters=5, warmup=3)
+    # the first frame of the shape again, with the executor's shape caches dropped and the allocator warm: what the
+    # POLICY costs (capacity unknown: wait for K, then map; mapper sequence unknown; no long-run record)
+    frame.release_caches()
+    torch.cuda.synchronize()
+    first = time.perf_counter()
+    step(); torch.cuda.synchronize()
+    out['first_frame_ms'] = (time.perf_counter() - first) * 1e3
+    for _ in range(3):
+      step()
+    torch.cuda.synchronize()
     key = frame._shape_key(dev, g.position.shape[0], size, cfg, None, False)
     out['frame_mapper'] = {_lib.MAPPER_DIRECT: 'direct', _lib.MAPPER_PRESORT: 'presort'}.get(frame._mapper_mode.get(key), '?')
     g.requires_grad_(False)
@@ -181,6 +203,59 @@ def measure(spec, dev):
   return out
 
 
+def measure_zoom(dev):
+  """One scene shape whose footprints alternate between two scales every three frames: overlaps per gaussian 3.0 <-> 4.4,
+  either side of the direct / pre-sort crossover (frame.PRESORT_ABOVE / DIRECT_BELOW).  The executor picks the sequence
+  from the PREVIOUS frame of the shape, so every switch is mapped once with the other sequence: reported per frame."""
+  from taichi_splatting_amd import RasterConfig, _lib, frame, render_gaussians
+  from taichi_splatting_amd.testing import random_camera, random_3d_gaussians
+  cfg = RasterConfig(tile_size=16)
+  n, side = 3_000_000, 2048
+  torch.manual_seed(0)
+  cam = random_camera(image_size=(side, side))
+  base = random_3d_gaussians(n, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  base = base.replace(feature=(torch.rand(n, 3, 16) - 0.5) * 0.5).to(dev)
+  cam = cam.to(device=dev)
+  variants = [base.replace(log_scaling=base.log_scaling + math.log(s)) for s in (1.25, 1.6)]
+  for v in variants:
+    v.requires_grad_(True)
+  frame.release_caches()
+  key = frame._shape_key(dev, n, (side, side), cfg, None, False)
+  rows = []
+  steady = []
+  for v in variants:                                   # each scale on its own, settled
+    def step(v=v):
+      for t in (v.position, v.log_scaling, v.rotation, v.alpha_logit, v.feature):
+        t.grad = None
+      return render_gaussians(v, cam, cfg, use_sh=True)
+    frame.release_caches()
+    for _ in range(4):
+      r = step(); r.image.sum().backward()
+    steady.append(cuda_ms(lambda: step().image.sum().backward(), iters=5, warmup=1))
+    rows.append(dict(K=frame.frame_status(r)['overlaps'], mapper=frame._mapper_mode.get(key)))
+  frame.release_caches()
+  times, modes = [], []
+  for i in range(18):
+    v = variants[(i // 3) % 2]
+    for t in (v.position, v.log_scaling, v.rotation, v.alpha_logit, v.feature):
+      t.grad = None
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    r = render_gaussians(v, cam, cfg, use_sh=True)
+    modes.append(int(r.frame.desc.mapper))
+    r.image.sum().backward()
+    b.record()
+    torch.cuda.synchronize()
+    times.append(a.elapsed_time(b))
+  frame.release_caches()
+  expect = [steady[(i // 3) % 2] for i in range(18)]
+  worst = max(t / e for t, e in zip(times[3:], expect[3:]))
+  return dict(name='zoom_3M_2048', K_per_N=[round(r['K'] / n, 2) for r in rows],
+              steady_ms=[round(x, 3) for x in steady], settled_mapper=[r['mapper'] for r in rows],
+              frame_ms=[round(t, 3) for t in times], frame_mapper=modes,
+              mean_over_steady=round(sum(times[3:]) / sum(expect[3:]), 3), worst_over_steady=round(worst, 3))
+
+
 def scenes(quick):
   specs = [dict(name='configD', kind='plain', n=6_000_000, side=2048, scale=1.0, alpha=(0.1, 0.9))]
   counts = {0.5: 6_000_000, 1.0: 6_000_000, 2.0: 6_000_000, 4.0: 2_000_000, 8.0: 1_000_000}
@@ -192,6 +267,10 @@ def scenes(quick):
         if quick and alpha[0] > 0.5 and scale != 2.0:
           continue
         specs.append(dict(name=f's{scale:g}_a{alpha[0]:g}_{side}', kind='plain', n=counts[scale], side=side, scale=scale, alpha=alpha))
+  for side in ((2048,) if quick else (1024, 2048, 4096)):
+    specs.append(dict(name=f'culled_s1_{side}', kind='plain', n=6_000_000, side=side, scale=1.0, alpha=(0.1, 0.9), margin=0.5))
+    specs.append(dict(name=f'needle_s0.5_{side}', kind='needle', n=6_000_000, side=side, scale=0.5, alpha=(0.1, 0.9)))
+  specs.append(dict(name='culled_needle_2048', kind='needle', n=6_000_000, side=2048, scale=0.7, alpha=(0.1, 0.9), margin=0.5))
   specs.append(dict(name='heavy_tail_2048', kind='heavy_tail', n=2_000_000, side=2048, scale=1.0, alpha=(0.1, 0.9)))
   specs.append(dict(name='pile_400k_2048', kind='pile', n=400_000, side=2048, scale=1.0, alpha=(0.1, 0.9)))
   specs.append(dict(name='dense2d_1024x768', kind='dense2d'))
@@ -222,6 +301,14 @@ def main():
     rows.append(r)
     print("SWEEP " + json.dumps(r), flush=True)
     torch.cuda.empty_cache()
+  zoom = None
+  if not args.only or 'zoom' in args.only:
+    try:
+      zoom = measure_zoom(dev)
+    except Exception as e:
+      zoom = dict(name='zoom_3M_2048', error=f"{type(e).__name__}: {e}"[:300])
+    print("SWEEP " + json.dumps(zoom), flush=True)
+    torch.cuda.empty_cache()
   ref = next((r for r in rows if r['name'] == 'configD' and 'error' not in r), None)
   lines = []
   head = f"{'scene':22s} {'N':>8s} {'K':>10s} {'K/N':>6s} {'K/tile':>7s} {'max run':>8s} | {'proj':>5s} {'sh':>5s} {'auto':>6s} {'dir':>6s} {'pre':>6s} {'fwd':>6s} {'bwd':>6s} {'frame':>6s} {'first':>7s} | {'map':>5s} {'fwd':>5s} {'bwd':>5s}  ps/overlap (x config D) | mapper  lists"
@@ -238,6 +325,8 @@ def main():
         flagged.append((r['name'], s, round(rel[s], 2)))
     if r['map_ms'] > 1.15 * r['map_best_ms'] + 0.02:
       flagged.append((r['name'], 'mapper-choice', round(r['map_ms'] / r['map_best_ms'], 2)))
+    if 'first_frame_ms' in r and r['first_frame_ms'] > FIRST_GUARD * r['frame_ms']:
+      flagged.append((r['name'], 'first-frame', round(r['first_frame_ms'] / r['frame_ms'], 2)))
     lines.append(f"{r['name']:22s} {r['N']:8d} {r['K']:10d} {r['K_per_N']:6.2f} {r['K_per_tile_mean']:7.0f} {r['K_per_tile_max']:8d} | "
                  f"{r['project_ms']:5.2f} {r['sh_ms']:5.2f} {r['map_auto_ms']:6.3f} {r['map_direct_ms']:6.3f} {r['map_presort_ms']:6.3f} "
                  f"{r['raster_fwd_ms']:6.3f} {r['raster_bwd_ms']:6.3f} {r.get('frame_ms', float('nan')):6.2f} {r.get('first_frame_ms', float('nan')):7.1f} | "
@@ -246,12 +335,22 @@ def main():
                  + (f"   long runs in segments (one workgroup per tile: fwd {r['raster_fwd_per_tile_ms']:.3f} bwd {r['raster_bwd_per_tile_ms']:.3f} ms)"
                     if 'raster_fwd_per_tile_ms' in r else ""))
   lines.append("")
-  lines.append(f"guard: cost per overlap of mapper / raster forward / raster backward <= {GUARD} x config D's")
+  lines.append("first = the first frame of the shape with the executor's shape caches cold and the allocator warm, wall time incl. "
+               "the final synchronise (ms); the very first frame of a shape in a fresh allocator: first_frame_wall_ms in the SWEEP lines")
+  if zoom is not None:
+    lines.append("")
+    lines.append(f"zoom path ({zoom['name']}): K/N {zoom.get('K_per_N')} settled on mapper {zoom.get('settled_mapper')} at {zoom.get('steady_ms')} ms; "
+                 f"alternating every 3 frames: frames {zoom.get('frame_ms')} mapper {zoom.get('frame_mapper')} -> mean {zoom.get('mean_over_steady')} x, "
+                 f"worst frame {zoom.get('worst_over_steady')} x its scale's steady frame" if 'error' not in zoom else f"zoom path ERROR {zoom['error']}")
+    if 'error' not in zoom and zoom['worst_over_steady'] > 1.3:
+      flagged.append((zoom['name'], 'zoom-worst-frame', zoom['worst_over_steady']))
+  lines.append(f"guard: cost per overlap of mapper / raster forward / raster backward <= {GUARD} x config D's; first frame <= {FIRST_GUARD} x steady; "
+               "zoom path worst frame <= 1.3 x steady")
   lines.append("flagged: " + (", ".join(f"{n}:{s} x{x}" for n, s, x in flagged) if flagged else "none"))
   text = "\n".join(lines)
   print(text)
   if args.out:
-    Path(args.out).write_text(text + "\n\n" + "\n".join("SWEEP " + json.dumps(r) for r in rows) + "\n")
+    Path(args.out).write_text(text + "\n\n" + "\n".join("SWEEP " + json.dumps(r) for r in rows + ([zoom] if zoom else [])) + "\n")
 
 
 if __name__ == '__main__':
