@@ -462,7 +462,9 @@ def test_new_sweep_shapes_lists_against_the_oracle(kind, tile):
   """Half-culled scenes (56 % of the gaussians outside the image: the compaction's int64 index list, N-sized buffers with
   V ~ N / 2 live rows) and needle splats (aspect ~10 at random orientations: the oriented-box test decides most tile
   candidates): the tile lists of both mapper sequences are identical to the numpy oracle's (tile, depth bits, point
-  index) order, and the frame executor — which never compacts — renders the image of the modular operators bit for bit."""
+  index) order, and the frame executor — which never compacts — renders the image of the modular operators (to float32
+  rounding: its sort keys come from ndc depths evaluated in double inside the key kernel, torch's float32 ndc values can
+  order two nearly coincident splats the other way round)."""
   from oracle import mapper as omap
   from taichi_splatting_amd import render_gaussians
   from taichi_splatting_amd.perspective.projection import project_to_image
@@ -494,7 +496,8 @@ def test_new_sweep_shapes_lists_against_the_oracle(kind, tile):
       r = render_gaussians(gd, camd, cfg, use_sh=False)
       o2p, ranges = map_to_tiles(g2d, ndc, size, cfg)
       want = rasterize_with_tiles(g2d, gd.feature[idx], o2p, ranges.view(-1, 2), size, cfg)
-    assert torch.equal(r.image, want.image) and torch.equal(r.image_weight, want.image_weight)
+    assert float((r.image - want.image).abs().max()) < 2e-6 and float((r.image_weight - want.image_weight).abs().max()) < 2e-6
+    assert float(want.image.max()) > 0.05
     assert int(frame.frame_status(r)['overlaps']) == want_o2p.shape[0]
     assert torch.equal(r.points.idx, idx)
   finally:
