@@ -162,16 +162,34 @@ __device__ __forceinline__ float pow_beta(float e, float log2_beta) { return e =
 // One visible point i, lane `sub` of its LPP-lane group.  TYPE: 0 scalar, 1 vector, 2 local_vector.  A lane owns the
 // pieces sub, sub + LPP, ... (KMAX of them) of VEC floats each: D <= LPP * KMAX * VEC.  Whole LPP groups are live or not,
 // so the shuffles stay uniform.
+// the per-point words every group of a step shares
+struct PointWords {
+  int64_t idx;      // row of the parameter arrays
+  float w;          // step weight (< 0: skip)
+  float tw;         // total weight (after this step's weight was added)
+  float gscale;     // gradient scale
+};
+
+__device__ __forceinline__ PointWords load_point_words(const CommonArgs& c, int64_t i, bool in_range) {
+  PointWords p;
+  p.w = in_range ? c.weight[i] : -1.0f;
+  const bool live = p.w >= 0.0f;                  // (NaN weights skip as well)
+  p.idx = live ? (c.indexes ? c.indexes[i] : i) : 0;
+  p.tw = live ? c.total_weight[p.idx] : 1.f;
+  p.gscale = (live && c.grad_scale) ? c.grad_scale[i] : 1.f;
+  return p;
+}
+
 template <int KIND, int TYPE, int LPP, int KMAX, int VEC>
-__device__ __forceinline__ void update_point(const GroupArgs& a, const CommonArgs& c, int64_t i, int sub, bool in_range) {
+__device__ __forceinline__ void update_point(const GroupArgs& a, const PointWords& pw, int64_t i, int sub) {
   static_assert(TYPE != 2 || (VEC == 1 && LPP == 4 && KMAX == 1), "local_vector rows are 2 or 3 floats");
   constexpr int E = KMAX * VEC;
-  const float w = in_range ? c.weight[i] : -1.0f;
-  const bool live = w >= 0.0f;                    // (NaN weights skip as well)
-  const int64_t idx = live ? (c.indexes ? c.indexes[i] : i) : 0;
+  const float w = pw.w;
+  const bool live = w >= 0.0f;
+  const int64_t idx = pw.idx;
   const int d = a.d;
-  const float tw = live ? c.total_weight[idx] : 1.f;
-  const float gscale = (live && c.grad_scale) ? c.grad_scale[i] : 1.f;
+  const float tw = pw.tw;
+  const float gscale = pw.gscale;
   const int64_t row = idx * d;
 
   float g[E], mo[E], pa[E], vo[TYPE == 0 ? E : 1];
@@ -294,7 +312,8 @@ template <int KIND, int TYPE, int LPP, int KMAX, int VEC>
 __global__ void __launch_bounds__(256)
 fractional_update_kernel(GroupArgs a, CommonArgs c) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  update_point<KIND, TYPE, LPP, KMAX, VEC>(a, c, t / LPP, (int)(t % LPP), t / LPP < c.m_count);
+  const int64_t i = t / LPP;
+  update_point<KIND, TYPE, LPP, KMAX, VEC>(a, load_point_words(c, i, i < c.m_count), i, (int)(t % LPP));
 }
 
 // Row shapes.  Rows whose length is a multiple of 4 floats (and whose arrays are 16-byte aligned) move as 16-byte
@@ -316,15 +335,25 @@ struct FusedArgs {
   int shape[MAX_FUSED_GROUPS];
 };
 
+// the workgroup's FUSED_POINTS points: their shared words are fetched ONCE into LDS (round 6, second step: with the index
+// list in global memory every pass of every group began with a dependent load — index, then rows — and the indexed step ran
+// 7 % behind the dense one)
+struct FusedShared {
+  int64_t idx[FUSED_POINTS];
+  float w[FUSED_POINTS], tw[FUSED_POINTS], gscale[FUSED_POINTS];
+};
+
 template <int KIND, int TYPE, int LPP, int KMAX, int VEC>
-__device__ __forceinline__ void fused_group(const GroupArgs& a, const CommonArgs& c, int64_t first) {
+__device__ __forceinline__ void fused_group(const GroupArgs& a, const CommonArgs& c, const FusedShared& sh, int64_t first) {
   constexpr int PER_PASS = 256 / LPP;
   const int sub = (int)(threadIdx.x % LPP), lane_point = (int)(threadIdx.x / LPP);
 #pragma unroll 1
   for (int p = 0; p < FUSED_POINTS; p += PER_PASS) {
-    const int64_t i = first + p + lane_point;
     if (first + p >= c.m_count) break;            // uniform over the workgroup
-    update_point<KIND, TYPE, LPP, KMAX, VEC>(a, c, i, sub, i < c.m_count);
+    const int q = p + lane_point;
+    PointWords pw;
+    pw.idx = sh.idx[q]; pw.w = sh.w[q]; pw.tw = sh.tw[q]; pw.gscale = sh.gscale[q];
+    update_point<KIND, TYPE, LPP, KMAX, VEC>(a, pw, first + q, sub);
   }
 }
 
@@ -332,15 +361,22 @@ template <int KIND>
 __global__ void __launch_bounds__(256)
 optim_fused_kernel(FusedArgs f) {
   const int64_t first = (int64_t)blockIdx.x * FUSED_POINTS;
+  __shared__ FusedShared sh;
+  {
+    const int64_t i = first + threadIdx.x;
+    const PointWords pw = load_point_words(f.c, i, i < f.c.m_count);
+    sh.idx[threadIdx.x] = pw.idx; sh.w[threadIdx.x] = pw.w; sh.tw[threadIdx.x] = pw.tw; sh.gscale[threadIdx.x] = pw.gscale;
+  }
+  __syncthreads();
 #pragma unroll 1
   for (int gi = 0; gi < f.num_groups; ++gi) {
     const GroupArgs& a = f.g[gi];
     const int type = f.type[gi];
-#define MS_FG(T, L, K, V) fused_group<KIND, T, L, K, V>(a, f.c, first)
+#define MS_FG(T, L, K, V) fused_group<KIND, T, L, K, V>(a, f.c, sh, first)
 #define MS_FT(L, K, V) do { if (type == 0) MS_FG(0, L, K, V); else MS_FG(1, L, K, V); } while (0)
     switch (f.shape[gi]) {
       case S_V1_L1: MS_FT(1, 1, 1); break;
-      case S_V1_L4: if (type == 2) MS_FG(2, 4, 1, 1); else MS_FT(4, 1, 1); break;
+      case S_V1_L4: MS_FT(4, 1, 1); break;
       case S_V1_L16: MS_FT(16, 1, 1); break;
       case S_V4_L1: MS_FT(1, 1, 4); break;
       case S_V4_L4: MS_FT(4, 1, 4); break;
@@ -509,7 +545,9 @@ extern "C" int ms_optim_step_groups(int kind, const ms_optim_group* groups, int 
     const int shape = pick_shape(g.group_type, a);
     // MS_OPTIM_FUSED=0 (read once): one launch per group, for A/B measurements of the fused launch
     static const bool allow_fused = [] { const char* e = getenv("MS_OPTIM_FUSED"); return !(e && e[0] == '0'); }();
-    const bool fusable = allow_fused && shape != S_V1_L16_K4 && shape != S_V1_L16_K16 && shape != S_V4_L16_K4;
+    // (local_vector groups keep a launch of their own as well: their 3 x 3 basis products cost the fused kernel 16 VGPRs
+    // and 9 KB of LDS — a wave per SIMD — for a group type a 3D model does not have)
+    const bool fusable = allow_fused && g.group_type != 2 && shape != S_V1_L16_K4 && shape != S_V1_L16_K16 && shape != S_V4_L16_K4;
     if (!fusable) {                                  // rows wider than 64 floats (or 16 unaligned): a launch of their own
       const int rc2 = launch_update(kind, g.group_type, a, c, s);
       if (rc2) return rc2;

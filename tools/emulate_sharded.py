@@ -414,7 +414,8 @@ def main_static(args):
     # (2) links charged, NOTHING overlapped: one forward collective, every collective blocks the step's stream
     st.exchange, st.exchange_async = make_exchanges(True)
     serial_ms.append(round(timed(step), 3))
-    # (3) links charged, what this round overlaps: geometry / colour collectives, the mapper runs beside the colours
+    # (3) the forward exchange as two collectives (this round), compute only: the split itself must cost nothing
+    st.exchange, st.exchange_async = make_exchanges(False)
     st.split_exchange = True
     overlapped_ms.append(round(timed(step), 3))
     stages_overlapped.append(stage_table())
@@ -436,18 +437,30 @@ def main_static(args):
   out["exchanged_bytes_per_rank"] = {"forward": W * cap * (9 + f_ch) * 4, "backward": W * cap * (7 + f_ch) * 4,
                                      "off_chip_fraction": round((W - 1) / W, 3)}
   out["link_model"] = link_model(W, [cap * (9 + f_ch) * 4, cap * (7 + f_ch) * 4], max(per_rank_graph), t_single)
+  # Overlap: a spin kernel on a SECOND stream does not model a busy link beside compute on this runtime — the streams share
+  # hardware queues and the spin kernel holds up the kernels queued behind it (measured: the "overlapped" step came out
+  # SLOWER than the serial one, 1.32 vs 1.24 ms, and 1.9 ms with GPU_MAX_HW_QUEUES=8).  So the serial figure is measured
+  # (spin kernels in line on the step's own stream, nothing beside them) and what the split exchange hides is arithmetic on
+  # measured stage times: the colour collective (col_ms) runs while the strip's unpack + mapper do (stage
+  # unpack_map_raster minus its raster forward ~ 0.17 ms on config E at N = 8) and is fully hidden; the geometry collective
+  # and the backward exchange stay exposed.
+  hidden = fwd_ms - geo_ms
+  with_overlap = [round(t - hidden, 3) for t in serial_ms]
   out["with_links"] = {
     "assumes": f"{LINK_GBS:g} GB/s per link and direction, the {W - 1} links of a rank busy at once, {LAUNCH_US:g} us per collective",
     "collective_ms": {"forward_one_collective": round(fwd_ms, 4), "forward_geometry": round(geo_ms, 4),
                       "forward_colours": round(col_ms, 4), "backward": round(bwd_ms, 4)},
-    "per_rank_ms_serial": serial_ms, "per_rank_ms_overlapped": overlapped_ms,
+    "per_rank_ms_serial_measured": serial_ms,
     "speedup_serial": round(t_single / max(serial_ms), 2),
-    "speedup_with_links": round(t_single / max(overlapped_ms), 2),
+    "per_rank_ms_split_exchange_compute_only": overlapped_ms,
+    "per_rank_ms_with_overlap": with_overlap,
+    "speedup_with_links": round(t_single / max(with_overlap), 2),
     "overlap_built": "forward exchange as two collectives: the strip's mapper runs while the colour rows travel "
                      "(ms_frame_inputs.colours_ready_event); the backward exchange is NOT overlapped",
-    "stage_ms_rank0_overlapped": stages_overlapped[0],
+    "stage_ms_rank0_split_exchange": stages_overlapped[0],
     # what hiding the backward exchange behind the raster backward band by band could still gain, at most: all of it
-    "bound_if_backward_exchange_were_free": round(t_single / (max(overlapped_ms) - bwd_ms), 2)}
+    "bound_if_backward_exchange_were_free": round(t_single / (max(with_overlap) - bwd_ms), 2),
+    "bound_if_every_collective_were_free": round(t_single / max(per_rank_graph), 2)}
   emit(args, out)
 
 
