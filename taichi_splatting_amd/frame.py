@@ -73,13 +73,17 @@ SPLIT_ALWAYS = os.environ.get('MS_SPLIT_ALWAYS', '0') not in ('', '0')
 BROADCAST_GRAD = os.environ.get('MS_BROADCAST_GRAD', '1') not in ('', '0')   # A/B switch of grad_image_broadcast
 STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays synchronise and raise on overflow
 
-# Eager frames that will be differentiated look at their overlap total LATE (round 6): the K word stays in its pinned
-# slot and is read at the NEXT frame's entry (or at the first host access to the frame's lists / status), so the backward of
-# frame i is enqueued while frame i's forward still runs and the host can be a whole frame ahead of the GPU — what a
-# HIP-graph replay gets for free.  Only for scene shapes whose capacity has not grown for LAZY_AFTER settled frames; an
-# overflow found late means that frame rendered the background and returned zero gradients: FrameOverflow is raised at
-# the point it is found (as a graph replay does).  MS_STRICT=1 / MS_LAZY_SETTLE=0: every frame waits before it returns.
-LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '1') not in ('', '0')
+# Eager frames that will be differentiated CAN look at their overlap total LATE (round 6; opt-in: MS_LAZY_SETTLE=1 or
+# frame.LAZY_SETTLE = True): the K word stays in its pinned slot and is read at the NEXT frame's entry (or at the first host
+# access to the frame's lists / status), so the backward of frame i is enqueued while frame i's forward still runs and the
+# host can be a whole frame ahead of the GPU — what a HIP-graph replay gets for free.  Only for scene shapes whose capacity
+# has not grown for LAZY_AFTER settled frames; an overflow found late means that frame rendered the background and returned
+# zero gradients: FrameOverflow is raised at the point it is found (as a graph replay does).
+# OFF by default: on config D the frame time is the same either way (3.216 against 3.219 ms on one box — the host's wait
+# was never what separates eager from a graph replay, the ~25 launch gaps are), while a trainer whose overlap total jumps
+# by more than K_SLACK between two frames of one shape (a new camera) would get an exception instead of round 5's
+# transparent re-run.  Worth switching on for loops with a slow host and steady overlap totals.
+LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '0') not in ('', '0')
 LAZY_AFTER = 3
 _stable_frames = {}       # scene-shape key -> settled frames in a row that fitted the remembered capacity
 _unsettled = collections.deque()   # FrameStates whose overlap total the host has not looked at yet (oldest first)

@@ -354,7 +354,8 @@ def _train_scene(n=30000, size=(320, 240), seed=3):
 
 
 def test_lazily_settled_frames_equal_settled_frames_and_do_not_wait():
-  """From the fourth frame of a scene shape on, a frame that will be differentiated is not settled before it returns:
+  """With frame.LAZY_SETTLE (opt-in), from the fifth frame of a scene shape on a frame that will be differentiated is not
+  settled before it returns:
   its backward is enqueued without a look at the overlap total (frame.host_syncs stays put), the look happens at the
   next frame's entry.  Images and gradients are bit for bit those of frames settled the round-5 way (MS_STRICT-like:
   LAZY_SETTLE off) — the kernels and their launch order are the same, only the host's wait moved."""
@@ -363,6 +364,7 @@ def test_lazily_settled_frames_equal_settled_frames_and_do_not_wait():
   cfg = RasterConfig()
   weight = torch.linspace(0.5, 1.5, 240 * 320 * 3, device=DEV).view(240, 320, 3)
   results = {}
+  default = frame.LAZY_SETTLE
   for lazy in (False, True):
     frame.release_caches()
     frame.LAZY_SETTLE = lazy
@@ -381,7 +383,7 @@ def test_lazily_settled_frames_equal_settled_frames_and_do_not_wait():
       frame.settle_all()
       results[lazy] = (outs, waits)
     finally:
-      frame.LAZY_SETTLE = True
+      frame.LAZY_SETTLE = default
       frame.release_caches()
   strict_waits, lazy_waits = results[False][1], results[True][1]
   assert all(w == (1, False) for w in strict_waits), strict_waits
@@ -404,6 +406,8 @@ def test_an_overflow_found_late_is_raised_not_swallowed():
   g, cam = _train_scene(seed=4)
   cfg = RasterConfig()
   frame.release_caches()
+  default = frame.LAZY_SETTLE
+  frame.LAZY_SETTLE = True
   try:
     for it in range(5):                                     # the shape settles: capacity known, stable
       gd = g.to(DEV).requires_grad_(True)
@@ -438,6 +442,7 @@ def test_an_overflow_found_late_is_raised_not_swallowed():
       r = render_gaussians(big.to(DEV), cam.to(device=DEV), cfg, use_sh=False)
     assert r.frame.pending is None and torch.equal(r.image, want)
   finally:
+    frame.LAZY_SETTLE = default
     frame.release_caches()
 
 
