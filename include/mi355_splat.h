@@ -299,7 +299,6 @@ int ms_raster_bwd_moments_split(const float* points7, const float* features, con
  * moments path) records the two hipEvent_t around its per-tile kernel on the stream it is launched on, then disarms.
  * bench.py times the dominant kernel INSIDE whole frames with it (roofline.kernel_ms); NULL, NULL disarms. */
 int ms_probe_raster_bwd(void* start_event, void* stop_event);
-int ms_probe_raster_bwd_armed(void);   /* != 0 while a probe waits for its launch */
 
 #define MS_SPLAT_ROW 16
 int ms_splat_rows_pack(const float* points7, const float* depth, const float* colours3, int64_t n, float* rows,
@@ -459,16 +458,6 @@ typedef struct ms_frame_grads {
 } ms_frame_grads;
 
 enum { MS_BOUNDARY_AXIS_SIGMA = 0, MS_BOUNDARY_COVARIANCE = 1 };
-
-/* Replayed launch sequences (round 6).  The launch sequence of ms_frame_project_count / ms_frame_map_raster /
- * ms_frame_backward is a function of the argument BYTES alone (descriptor, structs, block / output pointers, stream).  A
- * call whose bytes were seen before is captured once into a HIP graph (on a stream of the library's own) and replayed on
- * the caller's stream from then on — the ~25 launches of an eager frame then pay no launch gaps; calls with new bytes, callers
- * that are themselves capturing, frames with colours_ready_event or an armed probe, and any capture / replay failure run the
- * launches eagerly as before.  Results are those of the eager launches (same kernels, same order).  MS_FRAME_GRAPHS=0 in
- * the environment switches the cache off.  ms_frame_graph_stats: out4 = {replays, captures, eager calls, failures} since
- * the last reset; returns 1 when the cache is enabled. */
-int ms_frame_graph_stats(int64_t* out4, int reset);
 
 int ms_frame_layout_query(const ms_frame_desc* desc, ms_frame_layout* out);
 int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic);

@@ -165,8 +165,6 @@ SIGNATURES = {
   'ms_frame_map_raster': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC)] + [c_void_p] * 8),
   'ms_frame_backward': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, POINTER(FrameGradsC), c_void_p]),
   'ms_probe_raster_bwd': (c_int, [c_void_p, c_void_p]),
-  'ms_probe_raster_bwd_armed': (c_int, []),
-  'ms_frame_graph_stats': (c_int, [c_void_p, c_int]),
   'ms_optim_step_groups': (c_int, [c_int, POINTER(OptimGroupC), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
   'ms_optim_visibility_weights': (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float] + [c_void_p] * 5),
   'ms_raster_bwd': (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, POINTER(RasterConfigC)] + [c_void_p] * 3 + [c_int, c_int, c_int, c_void_p]),

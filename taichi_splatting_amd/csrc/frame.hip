@@ -13,8 +13,6 @@
 // A caller may still LOOK at K (k_host / k_event) — after everything is enqueued — to grow its buffers.
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <string>
 #include "common.h"
 #include "frame_internal.h"
 #include "raster_common.h"
@@ -223,130 +221,6 @@ extern "C" int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministi
     if (rc__ != 0) return rc__; \
   } while (0)
 
-// ---- replayed launch sequences (round 6) ----------------------------------------------------------------------------
-// An eager frame is ~25 launches, each followed by a 4-5 us gap that a HIP-graph replay of the same kernels does not pay
-// (config D: 3.22 ms eager against 3.08-3.11 as a replay, with or without the host's look at the overlap total).  The launch
-// SEQUENCE of each ms_frame_* call is a function of its arguments alone — that is what the executor was built for — so a call
-// whose argument bytes (descriptor, input / gradient structs, block and output pointers, stream) were seen before is
-// captured once on a stream of the library's own and replayed from then on: in a training loop torch's caching allocator
-// hands the same blocks to the same requests frame after frame.  Nothing is assumed: a call with new bytes runs its
-// launches eagerly (and is remembered), a capture or replay that fails falls back to eager launches, a caller that is
-// itself capturing (torch.cuda.graph, frame.FrameGraph) is left alone, and MS_FRAME_GRAPHS=0 switches the cache off.
-namespace {
-constexpr int GRAPH_SLOTS = 24, SEEN_SLOTS = 32;
-struct GraphSlot { uint64_t key = 0; hipGraphExec_t exec = nullptr; uint64_t stamp = 0; std::string bytes; };
-struct GraphCache {
-  std::mutex mu;
-  GraphSlot slot[GRAPH_SLOTS];
-  uint64_t seen[SEEN_SLOTS] = {};
-  int seen_pos = 0;
-  uint64_t clock = 0;
-  hipStream_t capture_stream = nullptr;
-  int64_t replays = 0, captures = 0, eager = 0, failures = 0;
-};
-GraphCache g_graphs;
-
-bool graphs_enabled() {
-  static const bool on = [] { const char* e = getenv("MS_FRAME_GRAPHS"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-uint64_t hash_bytes(uint64_t h, const void* p, size_t n) {
-  const unsigned char* b = (const unsigned char*)p;
-  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }      // FNV-1a
-  return h;
-}
-// the argument bytes of a call: a replay requires them EQUAL to the captured call's, not just equal hashes
-struct ArgBytes {
-  std::string b;
-  template <typename T> ArgBytes& add(const T& v) { b.append((const char*)&v, sizeof(T)); return *this; }
-  ArgBytes& add_bytes(const void* p, size_t n) { b.append((const char*)p, n); return *this; }
-  uint64_t hash() const { return hash_bytes(14695981039346656037ull, b.data(), b.size()); }
-};
-
-// body(stream) enqueues the call's launches on `stream` and returns 0 / an error code
-template <class F>
-int run_cached(hipStream_t user_stream, const ArgBytes& args, bool eligible, F&& body) {
-  if (!eligible || !graphs_enabled()) return body(user_stream);
-  uint64_t key = args.hash();
-  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(user_stream, &status) != hipSuccess || status != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return body(user_stream);                       // the caller captures the step itself
-  }
-  if (key == 0) key = 1;
-  std::unique_lock<std::mutex> lock(g_graphs.mu);
-  GraphCache& c = g_graphs;
-  for (GraphSlot& sl : c.slot) {
-    if (sl.key == key && sl.exec && sl.bytes == args.b) {
-      sl.stamp = ++c.clock;
-      const hipGraphExec_t exec = sl.exec;
-      if (hipGraphLaunch(exec, user_stream) == hipSuccess) { ++c.replays; return 0; }
-      (void)hipGetLastError();
-      (void)hipGraphExecDestroy(exec);
-      sl = GraphSlot{};
-      ++c.failures;
-      lock.unlock();
-      return body(user_stream);
-    }
-  }
-  bool seen_before = false;
-  for (uint64_t k : c.seen) seen_before |= k == key;
-  if (!seen_before) {
-    c.seen[c.seen_pos] = key; c.seen_pos = (c.seen_pos + 1) % SEEN_SLOTS;
-    ++c.eager;
-    lock.unlock();
-    return body(user_stream);
-  }
-  // second sight of these bytes: capture on the library's own stream (the caller's may be the legacy default stream,
-  // which cannot be captured), instantiate, replay on the caller's
-  if (!c.capture_stream && hipStreamCreateWithFlags(&c.capture_stream, hipStreamNonBlocking) != hipSuccess) {
-    (void)hipGetLastError();
-    ++c.failures;
-    lock.unlock();
-    return body(user_stream);
-  }
-  if (hipStreamBeginCapture(c.capture_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
-    (void)hipGetLastError();
-    ++c.failures;
-    lock.unlock();
-    return body(user_stream);
-  }
-  const int rc = body(c.capture_stream);
-  hipGraph_t graph = nullptr;
-  const hipError_t end = hipStreamEndCapture(c.capture_stream, &graph);
-  hipGraphExec_t exec = nullptr;
-  if (rc != 0 || end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    if (graph) (void)hipGraphDestroy(graph);
-    ++c.failures;
-    for (uint64_t& k : c.seen) if (k == key) k = 0;      // not tried again until the bytes come round twice more
-    lock.unlock();
-    return rc != 0 ? rc : body(user_stream);              // (an argument error is the same on either path)
-  }
-  (void)hipGraphDestroy(graph);
-  GraphSlot* victim = &c.slot[0];
-  for (GraphSlot& sl : c.slot) if (sl.stamp < victim->stamp) victim = &sl;
-  if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
-  *victim = GraphSlot{key, exec, ++c.clock, args.b};
-  ++c.captures;
-  if (hipGraphLaunch(exec, user_stream) == hipSuccess) return 0;
-  (void)hipGetLastError();
-  (void)hipGraphExecDestroy(exec);
-  *victim = GraphSlot{};
-  ++c.failures;
-  lock.unlock();
-  return body(user_stream);
-}
-}  // namespace
-
-extern "C" int ms_frame_graph_stats(int64_t* out4, int reset) {
-  std::lock_guard<std::mutex> lock(g_graphs.mu);
-  if (out4) { out4[0] = g_graphs.replays; out4[1] = g_graphs.captures; out4[2] = g_graphs.eager; out4[3] = g_graphs.failures; }
-  if (reset) g_graphs.replays = g_graphs.captures = g_graphs.eager = g_graphs.failures = 0;
-  return graphs_enabled() ? 1 : 0;
-}
-
 // per-gaussian forward stage into keep_n: camera position + projection (+ SH colours)
 static int frame_project_impl(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, bool projection,
                               bool colours, void* stream, const char* who) {
@@ -385,8 +259,8 @@ extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs
   return frame_project_impl(desc, in, keep_n, true, true, stream, "ms_frame_project");
 }
 
-static int frame_project_count_impl(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
-                                    void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
+extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
+                                      void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_project_count"));
   MS_TRY(check_inputs(in, "ms_frame_project_count"));
   MS_CHECK_ARG(in && keep_n && scratch_n, "null pointer");
@@ -450,9 +324,9 @@ static int frame_project_count_impl(const ms_frame_desc* desc, const ms_frame_in
   return 0;
 }
 
-static int frame_map_raster_impl(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
-                                 void* keep_k, void* scratch_k, void* out_image, void* out_alpha,
-                                 void* out_visibility, void* stream) {
+extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
+                                   void* keep_k, void* scratch_k, void* out_image, void* out_alpha,
+                                   void* out_visibility, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_map_raster"));
   MS_TRY(check_inputs(in, "ms_frame_map_raster"));
   MS_CHECK_ARG(in && keep_n && scratch_n && out_image && out_alpha, "null pointer");
@@ -526,8 +400,8 @@ static int frame_map_raster_impl(const ms_frame_desc* desc, const ms_frame_input
                            d.dtype, stream, cut ? &split : nullptr, in->longest_run_host);
 }
 
-static int frame_backward_impl(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
-                               const ms_frame_grads* gr, void* stream) {
+extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
+                                 const ms_frame_grads* gr, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_backward"));
   MS_TRY(check_inputs(in, "ms_frame_backward"));
   MS_TRY(check_grads(gr, "ms_frame_backward"));
@@ -618,49 +492,4 @@ static int frame_backward_impl(const ms_frame_desc* desc, const ms_frame_inputs*
   a.grad_position = gr->grad_position; a.grad_log_scaling = gr->grad_log_scaling; a.grad_rotation = gr->grad_rotation;
   a.grad_alpha_logit = gr->grad_alpha_logit; a.grad_feature = gr->grad_feature; a.grad_camera = gr->grad_camera;
   return gaussian_bwd_launch(a, s);
-}
-
-// ---- the three per-frame entry points: argument bytes -> key -> replay, capture or eager launches ------------------------
-static bool structs_hashable(const ms_frame_desc* desc, const ms_frame_inputs* in) {
-  return desc && in && desc->struct_size == sizeof(ms_frame_desc) && in->struct_size == sizeof(ms_frame_inputs) && desc->n > 0;
-}
-
-extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
-                                      void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
-  // (k_event: an event record of the caller's inside a replayed sequence is legal, but nobody passes one on this path)
-  const bool eligible = structs_hashable(desc, in) && k_event == nullptr;
-  ArgBytes args;
-  if (eligible)
-    args.add(1).add_bytes(desc, sizeof(*desc)).add_bytes(in, sizeof(*in)).add(keep_n).add(scratch_n).add(k_host).add(stream);
-  return run_cached((hipStream_t)stream, args, eligible, [&](hipStream_t s) {
-    return frame_project_count_impl(desc, in, keep_n, scratch_n, k_host, k_event, (void*)s);
-  });
-}
-
-extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
-                                   void* keep_k, void* scratch_k, void* out_image, void* out_alpha,
-                                   void* out_visibility, void* stream) {
-  // (an event of the caller's that the raster forward must wait for cannot join a captured sequence)
-  const bool eligible = structs_hashable(desc, in) && in->colours_ready_event == nullptr;
-  ArgBytes args;
-  if (eligible)
-    args.add(2).add_bytes(desc, sizeof(*desc)).add_bytes(in, sizeof(*in)).add(keep_n).add(scratch_n).add(keep_k).add(scratch_k)
-        .add(out_image).add(out_alpha).add(out_visibility).add(stream);
-  return run_cached((hipStream_t)stream, args, eligible, [&](hipStream_t s) {
-    return frame_map_raster_impl(desc, in, keep_n, scratch_n, keep_k, scratch_k, out_image, out_alpha, out_visibility, (void*)s);
-  });
-}
-
-extern "C" int ms_probe_raster_bwd_armed(void);
-
-extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* keep_k,
-                                 const ms_frame_grads* gr, void* stream) {
-  // (an armed measurement probe records the caller's events around the raster backward: eager launches for that frame)
-  const bool eligible = structs_hashable(desc, in) && gr && gr->struct_size == sizeof(ms_frame_grads) && !ms_probe_raster_bwd_armed();
-  ArgBytes args;
-  if (eligible)
-    args.add(3).add_bytes(desc, sizeof(*desc)).add_bytes(in, sizeof(*in)).add_bytes(gr, sizeof(*gr)).add(keep_n).add(keep_k).add(stream);
-  return run_cached((hipStream_t)stream, args, eligible, [&](hipStream_t s) {
-    return frame_backward_impl(desc, in, keep_n, keep_k, gr, (void*)s);
-  });
 }

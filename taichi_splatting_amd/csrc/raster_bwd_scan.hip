@@ -899,8 +899,6 @@ extern "C" int ms_probe_raster_bwd(void* start_event, void* stop_event) {
   return 0;
 }
 
-extern "C" int ms_probe_raster_bwd_armed(void) { return g_probe_start != nullptr || g_probe_stop != nullptr; }
-
 static int launch_scan_backward(const float* points7, const float* features,
                                 const int32_t* tile_ranges, const int32_t* overlap_to_point, const float* image,
                                 const float* grad_image, int image_w, int image_h, const ms_raster_config* cfg,

@@ -528,96 +528,3 @@ def test_first_frame_of_a_shape_maps_with_the_presort_and_carries_the_segments()
     assert torch.equal(first.frame.overlap_to_point()[:first.frame.k], second.frame.overlap_to_point()[:second.frame.k])
   finally:
     frame.release_caches()
-
-
-# ---- replayed launch sequences of the frame executor (csrc/frame.hip, round 6) -------------------------------------
-def _graph_stats(reset=False):
-  import ctypes as C
-  out = (C.c_int64 * 4)()
-  enabled = _lib.load().ms_frame_graph_stats(C.cast(out, C.c_void_p), int(reset))
-  return enabled, list(out)
-
-
-def test_replayed_launch_sequences_equal_eager_launches():
-  """From the third frame of a steady loop on (torch's caching allocator hands the same blocks to the same requests), the
-  three ms_frame_* calls of a frame replay HIP graphs captured from their own launch sequences instead of launching ~25
-  kernels one by one.  Same kernels, same order: the image is bit for bit the eager frame's, the gradients agree to the
-  order of their float atomics; the counters show replays and no failure; a step captured by the CALLER
-  (frame.FrameGraph) is left alone."""
-  from taichi_splatting_amd import render_gaussians
-  enabled, _ = _graph_stats(reset=True)
-  if not enabled:
-    pytest.skip("MS_FRAME_GRAPHS=0")
-  g, cam = _train_scene(n=40000, size=(320, 240), seed=12)
-  g = g.replace(feature=(torch.rand(40000, 3, 16) - 0.5) * 0.5)
-  cfg = RasterConfig()
-  gd, camd = g.to(DEV), cam.to(device=DEV)
-  gd.requires_grad_(True)
-  leaves = [gd.position, gd.log_scaling, gd.rotation, gd.alpha_logit, gd.feature]
-  weight = torch.linspace(0.5, 1.5, 240 * 320 * 3, device=DEV).view(240, 320, 3)
-  frame.release_caches()
-  try:
-    outs = []
-    for it in range(8):
-      for t in leaves:
-        t.grad = None
-      r = render_gaussians(gd, camd, cfg, use_sh=True)
-      (r.image * weight).sum().backward()
-      outs.append((r.image.detach().clone(), gd.position.grad.clone(), gd.feature.grad.clone()))
-      del r
-    torch.cuda.synchronize()
-    _, (replays, captures, eager, failures) = _graph_stats()
-    assert failures == 0 and captures >= 3 and replays >= 6, (replays, captures, eager, failures)
-    for later in outs[1:]:
-      assert torch.equal(later[0], outs[0][0])
-      for a, b in zip(later[1:], outs[0][1:]):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
-    assert float(outs[0][0].max()) > 0.05 and float(outs[0][1].abs().max()) > 0
-    # a caller's own capture of the whole step still works, and replays the same image
-    def step():
-      for t in leaves:
-        t.grad = None
-      r = render_gaussians(gd, camd, cfg, use_sh=True)
-      (r.image * weight).sum().backward()
-      return r
-    graph = frame.FrameGraph(step, warmup=2)
-    r = graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(r.image, outs[0][0])
-    del graph, r
-  finally:
-    frame.release_caches()
-
-
-def test_replayed_sequences_follow_changed_arguments():
-  """New argument bytes (another camera tensor, another scene size) are never served from a cached sequence: a frame whose
-  camera lives in a different tensor renders THAT camera, on eager launches."""
-  from taichi_splatting_amd import render_gaussians
-  from taichi_splatting_amd.testing import random_camera
-  enabled, _ = _graph_stats(reset=True)
-  if not enabled:
-    pytest.skip("MS_FRAME_GRAPHS=0")
-  g, cam = _train_scene(n=20000, size=(256, 192), seed=21)
-  cfg = RasterConfig()
-  gd = g.to(DEV)
-  torch.manual_seed(5)
-  cams = [cam.to(device=DEV), random_camera(image_size=(256, 192)).to(device=DEV)]
-  frame.release_caches()
-  try:
-    with torch.no_grad():
-      want = [render_gaussians(gd, c, cfg, use_sh=False).image.clone() for c in cams]
-      for it in range(10):
-        c = cams[it % 2]
-        got = render_gaussians(gd, c, cfg, use_sh=False).image
-        assert torch.equal(got, want[it % 2]), it
-        del got
-      # the camera VALUES change in place (a trainer's static camera buffer): the replay reads the new values
-      moving = cams[0]
-      moving.T_camera_world.copy_(cams[1].T_camera_world); moving.projection.copy_(cams[1].projection)
-      for it in range(4):
-        got = render_gaussians(gd, moving, cfg, use_sh=False).image
-        assert (got - want[1]).abs().max().item() < 1e-6, it
-    _, (replays, captures, eager, failures) = _graph_stats()
-    assert failures == 0, (replays, captures, eager, failures)
-  finally:
-    frame.release_caches()
