@@ -434,12 +434,15 @@ class ShardedStep(_RankStep):
     self.index_offset = int(index_offset)
     self.bucket_capacity = 0
     self.exchange = exchange or (lambda recv, send: _exchange_all_to_all(recv, send, self.group))
-    # Forward exchange as TWO collectives (round 6): geometry rows [packed 2D | depth | id] (36 bytes) first, colour rows
-    # (4 f bytes) behind them.  The strip's mapper reads geometry only, so it runs while the colours are on the links; the
-    # raster forward waits for them through an event (ms_frame_inputs.colours_ready_event).  exchange_async(recv, send)
-    # starts a collective and returns wait(), which makes the CURRENT stream wait for it.  MS_SPLIT_EXCHANGE=0: one collective.
+    # Forward exchange as TWO collectives (round 6, opt-in: split_exchange=True / MS_SPLIT_EXCHANGE=1): geometry rows
+    # [packed 2D | depth | id] (36 bytes) first, colour rows (4 f bytes) behind them.  The strip's mapper reads geometry only,
+    # so it runs while the colours are on the links; the raster forward waits for them through an event
+    # (ms_frame_inputs.colours_ready_event).  exchange_async(recv, send) starts a collective and returns wait(), which
+    # makes the CURRENT stream wait for it.  Off by default: at config E, N = 8 it hides 0.028 ms of modelled link time and
+    # its own side stream + event cost 0.03 ms in the emulation (profiles/r06_emul_sharded_8_4096.json) — it pays on slower
+    # links or more colour channels than three.
     import os
-    self.split_exchange = (os.environ.get('MS_SPLIT_EXCHANGE', '1') not in ('', '0')) if split_exchange is None else bool(split_exchange)
+    self.split_exchange = (os.environ.get('MS_SPLIT_EXCHANGE', '0') not in ('', '0')) if split_exchange is None else bool(split_exchange)
     if exchange is not None and exchange_async is None:
       # a caller that substitutes the blocking exchange (emulation, tests) gets it for both collectives
       def exchange_async(recv, send, _ex=exchange):
