@@ -1,7 +1,7 @@
 #!/bin/bash
 # The twelve one-GPU emulations of the multi-GPU rank steps (both decompositions, N = 2 / 4 / 8, configs D and E)
 #   tools/refresh_emulations.sh [tag]   ->   gpurun_out/<tag>_emul_{sharded,strips}_{N}_{size}.json
-tag=${1:-r05}
+tag=${1:-r06}
 for size in 2048 4096; do
   for w in 2 4 8; do
     python tools/emulate_sharded.py --static --world $w --size $size --steps 5 --warmup 2 --out gpurun_out/${tag}_emul_sharded_${w}_${size}.json > /dev/null 2>&1

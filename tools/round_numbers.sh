@@ -1,7 +1,5 @@
-B="python bench.py --no-cpu-baseline --steps 50"
+B="python bench.py --no-cpu-baseline --no-train-step --steps 50"
 pick() { grep -E "timed|stages" | sed 's/\[bench [0-9:]*\] //'; }
-echo "== stats (config D)"; MS_SPLAT_LIB=tools/abl/libstats.so python tools/ab_raster_bwd.py 2>&1 | grep -E "stats|V="
-echo "== stats (dense)"; MS_SPLAT_LIB=tools/abl/libstats.so python tools/ab_raster_bwd.py --dense 2>&1 | grep -E "stats|V="
 echo "== config D deterministic"; MS_DETERMINISTIC=1 $B 2>&1 | pick
 echo "== config D forward only"; $B --forward-only --no-stages 2>&1 | pick
 echo "== config C"; $B --n 1000000 --size 1920 --height 1080 2>&1 | pick
