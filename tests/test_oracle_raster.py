@@ -257,3 +257,28 @@ def test_non_blending_mode_accumulates_visibility():
   _, _, vis_blend = orast.forward(p, f, ranges, o2p, size, orast.Cfg())
   _, _, vis_median = orast.forward(p, f, ranges, o2p, size, orast.Cfg(use_alpha_blending=False, saturate_threshold=0.25))
   assert float(vis_blend.sum()) > 0 and torch.allclose(vis_blend, vis_median)
+
+
+def test_saturation_margin_known_answers():
+  """oracle.raster.saturation_margin (round 6): per splat, how close its nearest gated (pixel, splat) pair sits to the
+  backward's saturation test T_before <= 1 - saturate_threshold (backward.py:154,160), and on which side.  Four wide
+  splats over one tile, alpha 0.9 each (flat over the 8 x 8 tile to ~1e-4): T in front of them = 1, 0.1, 0.01, 0.001 ->
+  with saturate_threshold 0.99 (limit 0.01) the margins are 99, 9, ~0 (the gaussian's fall-off decides the side), 0.9."""
+  n = 4
+  p = torch.tensor([[4.0, 4.0, 1.0, 0.0, 400.0, 400.0, 0.9]] * n, dtype=torch.float64)
+  o2p, ranges = one_tile(n)
+  cfg = orast.Cfg(tile_size=8, saturate_threshold=0.99)
+  margin, side = orast.saturation_margin(p, ranges, o2p, (8, 8), cfg)
+  assert abs(margin[0].item() - 99.0) < 1e-2 and side[0].item() == 1
+  assert abs(margin[1].item() - 9.0) < 1e-2 and side[1].item() == 1
+  assert margin[2].item() < 1e-3                                      # T ~ 0.0100x: on the limit
+  assert abs(margin[3].item() - 0.9) < 1e-2 and side[3].item() == -1   # T ~ 0.001: dropped by the backward
+  # the backward really drops the fourth splat and keeps the second
+  f = torch.rand(n, 3, dtype=torch.float64)
+  img, _, _ = orast.forward(p, f, ranges, o2p, (8, 8), cfg)
+  gp, gf, _ = orast.backward(p, f, ranges, o2p, img, torch.ones_like(img), (8, 8), cfg)
+  assert float(gf[3].abs().max()) == 0.0 and float(gf[1].abs().max()) > 0
+  # a splat below the blend gate everywhere has no gated pair: margin inf, side 0
+  faint = torch.tensor([[4.0, 4.0, 1.0, 0.0, 2.0, 2.0, 0.001]], dtype=torch.float64)
+  m, s = orast.saturation_margin(faint, torch.tensor([[0, 1]], dtype=torch.int32), torch.arange(1, dtype=torch.int32), (8, 8), cfg)
+  assert math.isinf(m[0].item()) and s[0].item() == 0
