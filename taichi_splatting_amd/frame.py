@@ -576,9 +576,6 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
   state.pending, state.k_peek = settle, k_np
   if capacity == 0 or settle_now:
     settle()
-  else:
-    with _lock:
-      _unsettled.append(state)
 
 
 def settle_all():
@@ -960,7 +957,10 @@ def rasterize_frame(gaussians2d, depth, features, image_size, config: RasterConf
   state = FrameState()
   out = _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
                                       bool(use_depth16), state)
-  if not (out[0].requires_grad and state.key is not None and lazy_settle_allowed(state.key)):
+  if out[0].requires_grad and state.pending is not None and state.key is not None and lazy_settle_allowed(state.key):
+    with _lock:
+      _unsettled.append(state)
+  else:
     state.settle()
   return out
 
@@ -1027,7 +1027,10 @@ def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, u
   object.__setattr__(rendering, 'frame', state)
   # the host's look at the overlap total: last, behind everything it had to do anyway — or, for a frame that is about to
   # be differentiated on a scene shape with a settled capacity, not before the next frame (LAZY_SETTLE)
-  if not (image.requires_grad and state.key is not None and lazy_settle_allowed(state.key)):
+  if image.requires_grad and state.pending is not None and state.key is not None and lazy_settle_allowed(state.key):
+    with _lock:
+      _unsettled.append(state)     # looked at by the next frame's entry (settle_all) or the first host access
+  else:
     state.settle()
   return rendering
 

@@ -9,7 +9,7 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 python bench.py > "$out/bench.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-stages --no-graph --no-sweep > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o t -- python bench.py --steps 15 --warmup 3 --no-cpu-baseline --no-stages --no-graph --no-sweep --no-train-step > "$out/trace.log" 2>&1
 db=$(find "$out/trace" -name '*_results.db' | head -1)
 # the table covers the LAST 18 frames (3 warm-up + 15 timed, after the clock spin-up): steady state, like the bench line
 if [ -n "$db" ]; then python tools/rocpd_stats.py "$db" --last-steps 18 > "$out/kernel_trace.txt"; rm -f "$db"; fi
