@@ -274,13 +274,13 @@ def test_frame_executor_segments_vs_oracle():
 @pytest.mark.parametrize('tile,heuristics', [(16, False), (16, True), (32, False), (8, False)])
 def test_splat_row_entry_points_vs_oracle(tile, heuristics):
   """ms_splat_rows_pack -> ms_raster_fwd_rows -> ms_raster_bwd_moments_rows (one 64-byte row per splat gathered instead
-  of two dense arrays) against the oracle on BASELINE's config-A shape (10 000 random 2D gaussians, 256 x 256),
+  of two dense arrays) against the oracle at BASELINE config A's density (4 700 random 2D gaussians, 192 x 160),
   gate-stable: image, alpha, visibility, both gradients, heuristics.  Tile 8 offers the forward only."""
   lib = _lib.load()
-  size = (256, 256)
+  size = (192, 160)                  # (config A's density at 0.47 of its area: the oracle is most of this test's time)
   cfg = cfg_for(tile, compute_visibility=True, compute_point_heuristic=heuristics)
   torch.manual_seed(tile + (100 if heuristics else 0))
-  g0 = random_2d_gaussians(10000, size)
+  g0 = random_2d_gaussians(4700, size)
   p0 = project_gaussians2d(g0)
   o2p0, ranges0 = map_to_tiles(p0.to(DEV), g0.depths.reshape(-1, 1).to(DEV), size, cfg)
   keep = orast.gate_margin(p0.double(), ranges0.cpu(), o2p0.cpu(), size, cfg) > 1e-4

@@ -202,3 +202,48 @@ def test_sharded_step_in_a_hip_graph():
   assert torch.equal(image, want_image)
   good, worst = _close([t.grad for t in leaves], want, tol=1e-4)
   assert good, worst
+
+
+@pytest.mark.parametrize('use_sh', [True, False])
+def test_split_forward_exchange_equals_the_single_collective(use_sh):
+  """ShardedStep(split_exchange=True) (round 6, opt-in): the forward exchange as two collectives — geometry rows, then
+  colour rows that land directly in the strip's colour array while its mapper already runs; the raster forward waits for
+  them through ms_frame_inputs.colours_ready_event.  Same rows, same kernels: image bit for bit, gradients to the order
+  of the float atomics; and the step still captures into a HIP graph (fork / join through the side stream)."""
+  from taichi_splatting_amd import RasterConfig, frame, sharded
+  size = (256, 160)
+  g, cam, G = _scene(3, n=15000, size=size)
+  if not use_sh:
+    g = g.replace(feature=torch.rand(g.position.shape[0], 3))
+  cfg = RasterConfig()
+  loss_fn = lambda img, px: (img * G[px[0]:px[1]]).sum()
+  results = {}
+  for split in (False, True):
+    mine = g.to(DEV).requires_grad_(True)
+    step = sharded.ShardedStep(size, cfg, cam.depth_range, 0, 1, [0, 10], split_exchange=split)
+    step.probe(mine, cam, use_sh)
+    image, _ = step.step(mine, cam, loss_fn, use_sh=use_sh)
+    torch.cuda.synchronize()
+    assert step.comm_bytes['forward_collectives'] == (2 if split else 1)
+    assert not step.check()['bucket_overflow'] and not step.check()['overlap_overflow']
+    results[split] = (image.clone(), _grads(mine))
+  assert torch.equal(results[True][0], results[False][0]) and float(results[False][0].max()) > 0.05
+  good, worst = _close(results[True][1], results[False][1])
+  assert good, worst
+  # captured
+  mine = g.to(DEV).requires_grad_(True)
+  leaves = (mine.position, mine.log_scaling, mine.rotation, mine.alpha_logit, mine.feature)
+  step = sharded.ShardedStep(size, cfg, cam.depth_range, 0, 1, [0, 10], split_exchange=True)
+  step.probe(mine, cam, use_sh)
+
+  def one():
+    for t in leaves:
+      t.grad = None
+    return step.step(mine, cam, loss_fn, use_sh=use_sh)
+  graph = frame.FrameGraph(one, warmup=1)
+  for _ in range(2):
+    image, _ = graph.replay()
+  torch.cuda.synchronize()
+  assert torch.equal(image, results[False][0])
+  good, worst = _close([t.grad for t in leaves], results[False][1], tol=1e-4)
+  assert good, worst
