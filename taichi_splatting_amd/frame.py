@@ -80,7 +80,7 @@ STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays syn
 # has not grown for LAZY_AFTER settled frames; an overflow found late means that frame rendered the background and returned
 # zero gradients: FrameOverflow is raised at the point it is found (as a graph replay does).
 # OFF by default: on config D the frame time is the same either way (3.216 against 3.219 ms on one box — the host's wait
-# was never what separates eager from a graph replay, the ~25 launch gaps are), while a trainer whose overlap total jumps
+# was never what separates eager from a graph replay), while a trainer whose overlap total jumps
 # by more than K_SLACK between two frames of one shape (a new camera) would get an exception instead of round 5's
 # transparent re-run.  Worth switching on for loops with a slow host and steady overlap totals.
 LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '0') not in ('', '0')
