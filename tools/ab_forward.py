@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the raster forward kernel (config D scene) through the C-ABI: python tools/ab_forward.py [reps]
-(select a variant library with MS_SPLAT_LIB=tools/abl/lib<name>.so)"""
+(select a variant library with MS_SPLAT_LIB=tools/variants/lib<name>.so)"""
 import sys
 from pathlib import Path
 import torch

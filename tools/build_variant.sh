@@ -1,7 +1,7 @@
 #!/bin/bash
-# Build a development variant of libmi355_splat.so into tools/abl/lib<name>.so with extra hipcc flags:
+# Build a development variant of libmi355_splat.so into tools/variants/lib<name>.so with extra hipcc flags:
 #   tools/build_variant.sh stats -DMS_SCAN_STATS=1
-# Select it at run time with MS_SPLAT_LIB=tools/abl/lib<name>.so (taichi_splatting_amd/_lib.py).
+# Select it at run time with MS_SPLAT_LIB=tools/variants/lib<name>.so (taichi_splatting_amd/_lib.py).
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)

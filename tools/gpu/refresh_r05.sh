@@ -6,7 +6,7 @@ tools/ubench_blend.bin > $out/ubench_blend.txt 2>&1
 python tools/rbench.py --scene D --save /tmp/refD.pt --tag product > $out/rbench_product.txt 2>&1
 for v in stats phases abl1 abl2 commit1 commit2 commit3; do
   it=20; [ $v = stats ] && it=2
-  MS_SPLAT_LIB=tools/abl/lib$v.so python tools/rbench.py --scene D --ref /tmp/refD.pt --iters $it --tag $v > $out/rbench_$v.txt 2>&1
+  MS_SPLAT_LIB=tools/variants/lib$v.so python tools/rbench.py --scene D --ref /tmp/refD.pt --iters $it --tag $v > $out/rbench_$v.txt 2>&1
 done
 python tools/work_counters.py $out > $out/work.json
 tools/refresh_profiles.sh r05

@@ -7,7 +7,7 @@ out=${1:-gpurun_out/pmc_phases}
 mkdir -p "$out"
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 for name in default abl2 abl1 commit3; do
-  lib=""; [ "$name" != default ] && lib=tools/abl/lib$name.so
+  lib=""; [ "$name" != default ] && lib=tools/variants/lib$name.so
   pass() {
     p=$1; shift
     MS_SPLAT_LIB=$lib rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$name/$p" -o p -- \

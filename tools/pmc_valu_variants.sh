@@ -1,11 +1,11 @@
 #!/bin/bash
-# SQ_INSTS_VALU / SALU / LDS of the raster backward for several development variants (tools/abl/lib<name>.so):
+# SQ_INSTS_VALU / SALU / LDS of the raster backward for several development variants (tools/variants/lib<name>.so):
 #   tools/pmc_valu_variants.sh <outdir> name1 name2 ...
 out=$1; shift
 mkdir -p "$out"
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 for name in "$@"; do
-  lib=""; [ "$name" != default ] && lib=tools/abl/lib$name.so
+  lib=""; [ "$name" != default ] && lib=tools/variants/lib$name.so
   MS_SPLAT_LIB=$lib rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv \
     -d "$out/$name" -o p -- python tools/prof_raster.py 6000000 2048 16 2 > "$out/$name.log" 2>&1 || echo "$name failed"
   python - "$out/$name" "$name" <<'PY'

@@ -3,7 +3,7 @@
 backward kernels through the C-ABI on one scene, compares their outputs with a reference file written by an earlier
 run, and prints the -DMS_SCAN_STATS / -DMS_SCAN_PHASES counters when the loaded library has them.
 
-    MS_SPLAT_LIB=tools/abl/lib<name>.so python tools/rbench.py [--scene D|dense|C|...] [--save ref.pt | --ref ref.pt]
+    MS_SPLAT_LIB=tools/variants/lib<name>.so python tools/rbench.py [--scene D|dense|C|...] [--save ref.pt | --ref ref.pt]
 
 One JSON line per run on stdout (prefix RBENCH), so that a shell loop over variants gives a table.
 """
