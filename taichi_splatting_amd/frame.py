@@ -386,6 +386,7 @@ class FrameState:
     self.k_peek = None            # numpy view of the frame's pinned K word while `pending` is set
     self.consumed = False         # a backward pass was enqueued before the frame was settled
     self.key = None               # scene-shape key
+    self.lazy = False             # render_frame left the look at K to the next frame's entry (LAZY_SETTLE)
     self.captured = False         # enqueued under HIP-graph capture: k_word / k_view = the pinned word replays write K to
     self.k_word = self.k_view = None
     self.overflowed = 0           # largest overlap total a replay was seen to exceed the capacity with (sticky)
@@ -403,6 +404,9 @@ class FrameState:
     """Backward pass of a lazily settled frame: settle only if that costs no wait.  Returns False when the overlap total
     is not there yet — the backward is then enqueued on the frame as it is (see LAZY_SETTLE)."""
     if self.pending is None:
+      return True
+    if not self.lazy:
+      self.settle()                 # (a caller of the bare Function that has not settled: wait, as round 5 did)
       return True
     if self.k_peek is not None and int(self.k_peek[0]) == K_PENDING:
       self.consumed = True          # from here on a re-run of the forward could not repair this frame's gradients
@@ -958,6 +962,7 @@ def rasterize_frame(gaussians2d, depth, features, image_size, config: RasterConf
   out = _RasterizeFrameFunction.apply(gaussians2d, depth, features, tuple(int(x) for x in image_size), config,
                                       bool(use_depth16), state)
   if out[0].requires_grad and state.pending is not None and state.key is not None and lazy_settle_allowed(state.key):
+    state.lazy = True
     with _lock:
       _unsettled.append(state)
   else:
@@ -1028,6 +1033,7 @@ def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, u
   # the host's look at the overlap total: last, behind everything it had to do anyway — or, for a frame that is about to
   # be differentiated on a scene shape with a settled capacity, not before the next frame (LAZY_SETTLE)
   if image.requires_grad and state.pending is not None and state.key is not None and lazy_settle_allowed(state.key):
+    state.lazy = True
     with _lock:
       _unsettled.append(state)     # looked at by the next frame's entry (settle_all) or the first host access
   else:
