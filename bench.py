@@ -888,7 +888,7 @@ def graph_step_ms(g, cam, cfg, steps):
     render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
   graph = frame.FrameGraph(step, warmup=2)
   t_spin = time.perf_counter()
-  while time.perf_counter() - t_spin < 0.6:       # clock ramp, as for the eager measurement
+  while time.perf_counter() - t_spin < SPIN_UP_SECONDS:       # the same clock ramp as the eager measurement gets
     graph.replay()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
