@@ -40,7 +40,7 @@ if str(ROOT) not in sys.path:
   sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-SPIN_UP_SECONDS = 2.5       # single-GPU clock ramp before the warm-up steps (see the timed loop)
+SPIN_UP_SECONDS = float(os.environ.get('MS_BENCH_SPIN_SECONDS', '2.5'))       # single-GPU clock ramp before the warm-up steps (see the timed loop)
 
 
 def parse_args():
@@ -121,9 +121,15 @@ def algorithmic_bytes(N, V, K, P, T, F, D, passes):
   return b
 
 
-def cuda_time_ms(fn, iters=5, warmup=1):
-  for _ in range(warmup):
+def cuda_time_ms(fn, iters=5, warmup=1, ramp_s=0.04):
+  # untimed calls first: at least `warmup`, and for at least 40 ms — a GPU that idled for tens of milliseconds (a host-side
+  # allocation, a synchronise, Python's collector) runs its next ~10 frames' worth of work below its sustained clocks
+  # (tools/span_busy.py --each), which a 5-call measurement would otherwise be made of
+  t_ramp = time.perf_counter()
+  done = 0
+  while done < warmup or time.perf_counter() - t_ramp < ramp_s:
     fn()
+    done += 1
   torch.cuda.synchronize()
   start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   start.record()
@@ -399,45 +405,49 @@ def run_mode(mode, args, cfg, cam, scene, rank, world, device, distributed):
       dist.barrier()
     torch.cuda.synchronize()
 
-  # a GPU that sat idle while the scene was built runs its first ~0.2 s of work below its sustained clocks (the
-  # first process on a fresh box measures 5.4 ms/frame where the next one measures 3.6): spin it up with a fixed
-  # number of untimed frames (fixed, not time-based: every rank must run the same collectives) before the W warm-up
-  # steps the contract asks for
-  if mode == 'single' and args.spin_up > 0:
-    # one rank, no collectives: spin up by time.  2.5 s, not the 0.6 s of rounds 2-4: the FIRST process on a fresh box
-    # timed 3.31 ms / frame behind 0.6 s of frames and 3.02 for the graph replay seven seconds later, the second process
-    # 3.07 (profiles/r05_bench_cold_start.txt) — the clocks of a cold chip take seconds, not tenths, to settle
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < SPIN_UP_SECONDS:
-      step()
-  else:
-    # (a dry run checks the collectives, not the clocks: its steps go through the host)
-    for _ in range(min(args.spin_up, 20) if args.dry_run else args.spin_up):
-      step()
-  torch.cuda.synchronize()
-  for i in range(args.warmup):
-    step()
-  torch.cuda.synchronize()
-  log(f"[{mode}] spin-up + {args.warmup} warmup steps done")
-  run = step
-  if static is not None and args.rank_graph:
-    from taichi_splatting_amd import frame as frame_mod0
-    # one captured step per view, replayed round robin
-    graphs = [frame_mod0.FrameGraph(lambda v=v: step_view(v), warmup=1) for v in range(n_views)]
-    counter[0] = 0
-
-    def run():
-      graphs[counter[0] % n_views].replay()
-      counter[0] += 1
-    comm['hip_graph'] = True
-
   from taichi_splatting_amd import frame as frame_mod
-  # The interpreter's cyclic collector is parked for the timed region: a generation-2 pass over torch's ~10^6 tracked
-  # objects stops the host for 35-45 ms — ten frames — once every couple of hundred frames, and the GPU queue holds
-  # three (tools/host_overhead.py: frame intervals median 3.40 ms, max 44 ms with the collector, 11 ms without).
+  # The interpreter's cyclic collector is parked for spin-up, warm-up AND the timed region: a generation-2 pass over torch's
+  # ~10^6 tracked objects stops the host for 35-45 ms — ten frames — once every couple of hundred frames, and the GPU queue
+  # holds three (tools/host_overhead.py: frame intervals median 3.40 ms, max 44 ms with the collector, 11 ms without).
   # Nothing is skipped: reference counting still frees every tensor of a frame as the frame ends
   # (taichi_splatting_amd.frame.parked_gc, what a training loop on this back end would wrap its epoch in).
+  #
+  # Round 6: the collector is parked BEFORE the spin-up, not between the warm-up and the timed steps.  Parking it runs one
+  # full collection (30-50 ms of host time), and a GPU left idle that long drops its clocks and needs ~10 frames to get
+  # them back: under the tracer the first timed frames ran 3.54 / 3.68 / 3.37 / 3.26 / 3.21 / 3.16 ms before settling at
+  # 2.99 (tools/span_busy.py --each, session L), +0.13 ms per step over K = 20 steps on boxes whose clocks ramp slowly —
+  # the whole of what looked like an eager-vs-graph gap (the graph child never paused there).  Between the last warm-up
+  # step and the first timed step there is now only what the contract puts there: a barrier and a synchronise.
   with frame_mod.parked_gc():
+    # a GPU that sat idle while the scene was built runs its first ~0.2 s of work below its sustained clocks (the
+    # first process on a fresh box measures 5.4 ms/frame where the next one measures 3.6): spin it up with a fixed
+    # number of untimed frames (fixed, not time-based: every rank must run the same collectives) before the W warm-up
+    # steps the contract asks for
+    if mode == 'single' and args.spin_up > 0:
+      # one rank, no collectives: spin up by time.  2.5 s, not the 0.6 s of rounds 2-4: the FIRST process on a fresh box
+      # timed 3.31 ms / frame behind 0.6 s of frames and 3.02 for the graph replay seven seconds later, the second process
+      # 3.07 (profiles/r05_bench_cold_start.txt) — the clocks of a cold chip take seconds, not tenths, to settle
+      t_spin = time.perf_counter()
+      while time.perf_counter() - t_spin < SPIN_UP_SECONDS:
+        step()
+    else:
+      # (a dry run checks the collectives, not the clocks: its steps go through the host)
+      for _ in range(min(args.spin_up, 20) if args.dry_run else args.spin_up):
+        step()
+    torch.cuda.synchronize()
+    run = step
+    if static is not None and args.rank_graph:
+      # one captured step per view, replayed round robin
+      graphs = [frame_mod.FrameGraph(lambda v=v: step_view(v), warmup=1) for v in range(n_views)]
+      counter[0] = 0
+
+      def run():
+        graphs[counter[0] % n_views].replay()
+        counter[0] += 1
+      comm['hip_graph'] = True
+    log(f"[{mode}] spin-up done, {args.warmup} warm-up + {args.steps} timed steps follow")
+    for i in range(args.warmup):
+      run()
     barrier()
     syncs0 = frame_mod.host_syncs + frame_mod.point_syncs
     entry0, settles0 = frame_mod.entry_waits, frame_mod.settles
@@ -913,12 +923,12 @@ def tile_step_ms(g, cam, tile, steps):
     for t in leaves:
       t.grad = None
     render_gaussians(g, cam, cfg, use_sh=True).image.sum().backward()
-  t_spin = time.perf_counter()
-  while time.perf_counter() - t_spin < 0.3:
-    step()
-  torch.cuda.synchronize()
   from taichi_splatting_amd import frame
-  with frame.parked_gc():                    # as in the timed region of run_mode
+  with frame.parked_gc():                    # as in run_mode: parked BEFORE the ramp (its collection idles the GPU for 30-50 ms)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.3:
+      step()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
       step()
@@ -956,12 +966,13 @@ def in_frame_kernel_ms(g, cam, cfg, frames=12):
   g.requires_grad_(True)
   leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
   pairs = []
-  for i in range(frames + 3):
+  lead = 12                                  # untimed frames first: the clocks are back up behind whatever ran before
+  for i in range(frames + lead):
     for t in leaves:
       t.grad = None
     r = render_gaussians(g, cam, cfg, use_sh=True)
     loss = r.image.sum()
-    if i >= 3:
+    if i >= lead:
       a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       a.record(); b.record()                      # (torch creates the hipEvent_t at the first record; the library re-records both)
       pairs.append((a, b))
@@ -1020,8 +1031,11 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
     params.step(indexes=None, visibility=frame.point_outputs(r)['visibility'])
 
   def timed(fn, k):
-    torch.cuda.synchronize()
     with frame.parked_gc():
+      t_ramp = time.perf_counter()             # (the collection that parks the collector idled the GPU: clocks back up first)
+      while time.perf_counter() - t_ramp < 0.15:
+        fn()
+      torch.cuda.synchronize()
       t0 = time.perf_counter()
       for _ in range(k):
         fn()

@@ -204,10 +204,13 @@ def main_strips(args):
 
   def timed(fn, steps=None):
     steps = steps or max(args.steps, 20)
-    for _ in range(max(args.warmup, 10)):
-      fn()
-    torch.cuda.synchronize()
-    with frame.parked_gc():
+    with frame.parked_gc():                 # parked BEFORE the warm-up: its collection idles the GPU for 30-50 ms (bench.py)
+      t_ramp = time.perf_counter()
+      while time.perf_counter() - t_ramp < 0.1:
+        fn()
+      for _ in range(max(args.warmup, 10)):
+        fn()
+      torch.cuda.synchronize()
       t0 = time.perf_counter()
       for _ in range(steps):
         fn()
@@ -281,10 +284,13 @@ def main_static(args):
 
   def timed(fn, steps=None):
     steps = steps or max(args.steps, 20)
-    for _ in range(max(args.warmup, 10)):
-      fn()
-    torch.cuda.synchronize()
-    with frame.parked_gc():                 # as bench.py: a generation-2 collection inside 20 steps reads as +2 ms
+    with frame.parked_gc():                 # parked BEFORE the warm-up: its collection idles the GPU for 30-50 ms (bench.py)
+      t_ramp = time.perf_counter()
+      while time.perf_counter() - t_ramp < 0.1:
+        fn()
+      for _ in range(max(args.warmup, 10)):
+        fn()
+      torch.cuda.synchronize()
       t0 = time.perf_counter()
       for _ in range(steps):
         fn()
