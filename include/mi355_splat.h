@@ -201,27 +201,6 @@ int ms_find_ranges(const void* sorted_keys, int64_t k, int key_bytes, int tile_s
 int ms_tile_depth_sort(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys,
                        int32_t* overlap_to_point, uint64_t* scratch, void* stream);
 
-/* Tile bins (round 6): the same overlap lists by a counting sort on the tile id — no radix pass over the overlaps.
- *   ms_tile_histogram        tile_counts[tile] += 1 for every (gaussian, tile) overlap (tile_overlaps_kernel's test,
- *                            tile_mapper.py:76-86, counted per TILE instead of per gaussian).  tile_counts (num_tiles)
- *                            int32 must be zero on entry.  An exclusive scan of it (ms_exclusive_scan_i32) is the start
- *                            of every tile's run and, at [num_tiles], the overlap total: tile_ranges without ms_find_ranges.
- *   ms_tile_emit_bins        generate_sort_keys_kernel (tile_mapper.py:115-146) writing depth key << 32 | point index
- *                            (the 32 bit key of ms_tile_emit_keys64) at tile_cursor[tile]++: tile_cursor (num_tiles) int32
- *                            holds the run starts on entry and the run ends on return.  Slots >= capacity are not written.
- *                            The order INSIDE a run depends on the scheduling of the launch;
- *   ms_tile_depth_sort_pairs puts every run into (depth key, point index) order — all pairs differ, so the result does
- *                            not depend on that scheduling and equals ms_tile_depth_sort's — and writes the point indices
- *                            to overlap_to_point.  pairs is scratch afterwards; `scratch`: K more u64 words. */
-int ms_tile_histogram(const float* points7, int64_t v, int image_w, int image_h, int tile_size, float alpha_threshold,
-                      int tile_row_begin, int tile_row_end, int32_t* tile_counts, void* stream);
-int ms_tile_emit_bins(const float* points7, const void* depth, int depth_dtype, int64_t v, int image_w, int image_h,
-                      int tile_size, float alpha_threshold, int tile_row_begin, int tile_row_end, int depth16,
-                      double ndc_near, double ndc_far, int64_t capacity, int32_t* tile_cursor, uint64_t* out_pairs,
-                      void* stream);
-int ms_tile_depth_sort_pairs(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* pairs, int32_t* overlap_to_point,
-                             uint64_t* scratch, void* stream);
-
 /* ---- rasterizer ------------------------------------------------------------------------------
  * _forward_kernel (rasterizer/forward.py:23-135).  points7 (V,7), features (V,F), tile_ranges
  * (T,2) int32 indexed by tile id = tx + ty * ceil(W/tile), overlap_to_point (K) int32.

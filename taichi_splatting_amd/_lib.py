@@ -136,9 +136,6 @@ SIGNATURES = {
   'ms_segmented_sort_pairs': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
   'ms_find_ranges': (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
   'ms_tile_depth_sort': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-  'ms_tile_depth_sort_pairs': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-  'ms_tile_histogram': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
-  'ms_tile_emit_bins': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int64, c_void_p, c_void_p, c_void_p]),
   'ms_fractional_step': (c_int, [c_int, c_int] + [c_void_p] * 7 + [c_int64, c_int, c_float, c_float, c_float, c_float, c_int, c_void_p]),
   'ms_morton_codes64': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
   'ms_camera_position': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -94,15 +94,6 @@ void tile_emit_direct_launch(const float* points7, const void* depth, int dtype,
 // run_stats (device, three zeroed words, or NULL): [2] = "a per-tile kernel declined a run" (NULL: the long-run kernel
 // reads every run's mark; [0], [1] unused).  run_host (pinned, may be NULL) receives the length of a run above 16384
 // entries if there is one.
-void tile_histogram_launch(const float* points7, const void* cull_depth, int dtype, int64_t v, int image_w, int image_h,
-                           int tile_size, float alpha_threshold, int row_begin, int row_end, int32_t* tile_counts,
-                           hipStream_t s);
-void tile_emit_bins_launch(const float* points7, const void* depth, int dtype, int cull, int64_t v, int image_w, int image_h,
-                           int tile_size, float alpha_threshold, int row_begin, int row_end, int depth16, double ndc_near,
-                           double ndc_far, const int32_t* k_limit_dev, int64_t capacity, int32_t* cursor, uint64_t* out_pairs,
-                           hipStream_t s);
-void tile_depth_sort_pairs_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* pairs, int32_t* overlap_to_point,
-                                  uint64_t* scratch, hipStream_t s, int32_t* run_stats = nullptr, int32_t* run_host = nullptr);
 void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
                             uint64_t* scratch, hipStream_t s, int32_t* run_stats = nullptr, int32_t* run_host = nullptr);
 

@@ -230,53 +230,6 @@ tile_emit_direct_kernel(const float* __restrict__ points, const T* __restrict__ 
   });
 }
 
-// ---- frame executor, tile bins (round 6): a counting sort on the tile id instead of a radix sort.  Pass one counts the
-// overlaps PER TILE (one atomic per overlap on a table of num_tiles words), an exclusive scan of that table is already
-// tile_ranges and the overlap total, pass two claims a slot of the tile's run with one returning atomic per overlap and
-// writes depth key << 32 | point index there.  The order inside a run is whatever the atomics made it; the per-tile sort
-// (tile_sort.hip, packed mode) orders the 64 bit pairs, which are all different, so the result is the (tile, depth key,
-// point index) order of the other two sequences bit for bit.  Bytes per overlap: 8 written + 8 read by the tile sort,
-// against 92 for the direct sequence's two radix passes.
-template <typename T>
-__global__ void __launch_bounds__(256, 8)
-tile_histogram_kernel(const float* __restrict__ points, const T* __restrict__ cull_depth, int64_t v, int image_w,
-                      int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end,
-                      int32_t* __restrict__ tile_counts) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < v && !(cull_depth && !(cull_depth[i] > T(0)));      // same rule as DepthPairs::key
-  float g[7] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f, 0.f};
-  if (valid) load_point7(points, i, g);
-  const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
-  const int tiles_wide = image_w / tile_size;
-  emit_span(q, valid, 0, tile_size, row_begin, row_end, [&](int64_t, int tx, int ty, int) {
-    atomicAdd(tile_counts + ((int64_t)tx + (int64_t)ty * tiles_wide), 1);
-  });
-}
-
-// cursor[tile]: start of the tile's run on entry (the exclusive scan of the counts), its end on return
-template <typename T>
-__global__ void __launch_bounds__(256)
-tile_emit_bins_kernel(const float* __restrict__ points, const T* __restrict__ depth, int cull, int64_t v, int image_w,
-                      int image_h, int tile_size, float alpha_threshold, int row_begin, int row_end, int depth16,
-                      double near_plane, double far_plane, const int32_t* __restrict__ k_limit, int64_t capacity,
-                      int32_t* __restrict__ cursor, uint64_t* __restrict__ pairs) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k_limit && *k_limit == 0) return;                // overflow of the caller's capacity: write nothing (uniform)
-  const bool valid = i < v && !(cull && !(depth[i] > T(0)));
-  float g[7] = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f, 0.f};
-  if (valid) load_point7(points, i, g);
-  const ObbQuery q = obb_grid_query(g, image_w, image_h, tile_size, alpha_threshold);
-  const int tiles_wide = image_w / tile_size;
-  const uint32_t depth_key = valid ? (uint32_t)depth_sort_key(depth[i], depth16, near_plane, far_plane) : 0u;
-  emit_span(q, valid, 0, tile_size, row_begin, row_end, [&](int64_t, int tx, int ty, int from) {
-    uint32_t dk = depth_key;
-    int32_t who = (int32_t)i;
-    if (from >= 0) { dk = (uint32_t)__builtin_amdgcn_readlane((int)depth_key, from); who = __builtin_amdgcn_readlane((int32_t)i, from); }
-    const int64_t o = atomicAdd(cursor + ((int64_t)tx + (int64_t)ty * tiles_wide), 1);
-    if (o < capacity) pairs[o] = ((uint64_t)dk << 32) | (uint32_t)who;
-  });
-}
-
 // 32 bit sort keys of the depth pre-sort: float bits (non-negative depths) or the 16 bit quantisation.
 // near_plane > 0 fuses ndc_depth (torch_lib/projection.py:120-123, renderer.py:67): evaluated in double
 // from the depth's own precision, then rounded once to the float the key is made of.
@@ -331,33 +284,6 @@ void tile_emit_direct_launch(const float* points7, const void* depth, int dtype,
     tile_emit_direct_kernel<float><<<grid, block, 0, s>>>(points7, (const float*)depth, cum, v, image_w, image_h, tile_size,
                                                           alpha_threshold, row_begin, row_end, depth16, ndc_near, ndc_far,
                                                           k_limit_dev, out_keys, out_values);
-}
-
-void tile_histogram_launch(const float* points7, const void* cull_depth, int dtype, int64_t v, int image_w, int image_h,
-                           int tile_size, float alpha_threshold, int row_begin, int row_end, int32_t* tile_counts,
-                           hipStream_t s) {
-  const dim3 grid((unsigned)div_up(v, 256)), block(256);
-  if (dtype == MS_F64)
-    tile_histogram_kernel<double><<<grid, block, 0, s>>>(points7, (const double*)cull_depth, v, image_w, image_h, tile_size,
-                                                         alpha_threshold, row_begin, row_end, tile_counts);
-  else
-    tile_histogram_kernel<float><<<grid, block, 0, s>>>(points7, (const float*)cull_depth, v, image_w, image_h, tile_size,
-                                                        alpha_threshold, row_begin, row_end, tile_counts);
-}
-
-void tile_emit_bins_launch(const float* points7, const void* depth, int dtype, int cull, int64_t v, int image_w, int image_h,
-                           int tile_size, float alpha_threshold, int row_begin, int row_end, int depth16, double ndc_near,
-                           double ndc_far, const int32_t* k_limit_dev, int64_t capacity, int32_t* cursor, uint64_t* out_pairs,
-                           hipStream_t s) {
-  const dim3 grid((unsigned)div_up(v, 256)), block(256);
-  if (dtype == MS_F64)
-    tile_emit_bins_kernel<double><<<grid, block, 0, s>>>(points7, (const double*)depth, cull, v, image_w, image_h, tile_size,
-                                                         alpha_threshold, row_begin, row_end, depth16, ndc_near, ndc_far,
-                                                         k_limit_dev, capacity, cursor, out_pairs);
-  else
-    tile_emit_bins_kernel<float><<<grid, block, 0, s>>>(points7, (const float*)depth, cull, v, image_w, image_h, tile_size,
-                                                        alpha_threshold, row_begin, row_end, depth16, ndc_near, ndc_far,
-                                                        k_limit_dev, capacity, cursor, out_pairs);
 }
 
 }  // namespace ms
@@ -436,37 +362,6 @@ extern "C" int ms_tile_emit_keys64(const float* points7, const void* depth, int 
   tile_emit_direct_launch(points7, depth, depth_dtype, cum, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin,
                           tile_row_end, depth16, ndc_near > 0.0 ? ndc_near : 0.0, ndc_far, nullptr, out_keys, out_values,
                           (hipStream_t)stream);
-  MS_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int ms_tile_histogram(const float* points7, int64_t v, int image_w, int image_h, int tile_size,
-                                 float alpha_threshold, int tile_row_begin, int tile_row_end, int32_t* tile_counts,
-                                 void* stream) {
-  MS_CHECK_ARG(v >= 0, "v < 0");
-  MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
-  MS_CHECK_ARG(image_w % tile_size == 0 && image_h % tile_size == 0, "image size must be padded to the tile size");
-  if (v == 0) return 0;
-  MS_CHECK_ARG(points7 && tile_counts, "null pointer");
-  tile_histogram_launch(points7, nullptr, MS_F32, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin, tile_row_end,
-                        tile_counts, (hipStream_t)stream);
-  MS_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int ms_tile_emit_bins(const float* points7, const void* depth, int depth_dtype, int64_t v, int image_w,
-                                 int image_h, int tile_size, float alpha_threshold, int tile_row_begin, int tile_row_end,
-                                 int depth16, double ndc_near, double ndc_far, int64_t capacity, int32_t* tile_cursor,
-                                 uint64_t* out_pairs, void* stream) {
-  MS_CHECK_ARG(v >= 0 && capacity >= 0, "v < 0 or capacity < 0");
-  MS_CHECK_ARG(depth_dtype == MS_F32 || depth_dtype == MS_F64, "depth_dtype must be MS_F32 or MS_F64");
-  MS_CHECK_ARG(tile_size > 0 && image_w > 0 && image_h > 0, "bad image/tile size");
-  MS_CHECK_ARG(image_w % tile_size == 0 && image_h % tile_size == 0, "image size must be padded to the tile size");
-  if (v == 0) return 0;
-  MS_CHECK_ARG(points7 && depth && tile_cursor && (out_pairs || capacity == 0), "null pointer");
-  tile_emit_bins_launch(points7, depth, depth_dtype, 0, v, image_w, image_h, tile_size, alpha_threshold, tile_row_begin,
-                        tile_row_end, depth16, ndc_near > 0.0 ? ndc_near : 0.0, ndc_far, nullptr, capacity, tile_cursor,
-                        out_pairs, (hipStream_t)stream);
   MS_CHECK_LAUNCH();
   return 0;
 }

@@ -93,23 +93,13 @@ __device__ __forceinline__ uint32_t ts_block_exclusive(uint32_t v, uint32_t* red
 // ---- bounded path: LSD radix sort of one run by the whole workgroup, on global memory ------------------------------
 // srt[b .. b + n): tile << 32 | depth key; o2p[b .. b + n): point indices (ascending); alt: scratch of the same extent.
 // wcnt: TS_WAVES * 256 words of LDS (per-wave digit counters, then write positions)
-// packed: srt[b .. b + n) holds depth key << 32 | point index in ANY order (the tile-bins mapper); the point indices
-// are then digits of the sort as well (the ones that vary).
 __device__ void tile_radix_sort_global(uint64_t* srt, int32_t* o2p, uint64_t* alt,
-                                       int64_t b, int n, TsShared& sh, uint32_t* wcnt, bool packed) {
+                                       int64_t b, int n, TsShared& sh, uint32_t* wcnt) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  uint32_t kor = 0u, kand = 0xffffffffu, ior = 0u, iand = 0xffffffffu;
+  uint32_t kor = 0u, kand = 0xffffffffu;
   for (int i = t; i < n; i += TS_THREADS) {
-    uint32_t k;
-    if (packed) {
-      const uint64_t p = srt[b + i];
-      k = (uint32_t)(p >> 32);
-      ior |= (uint32_t)p;
-      iand &= (uint32_t)p;
-    } else {
-      k = (uint32_t)srt[b + i];
-      srt[b + i] = ((uint64_t)k << 32) | (uint32_t)o2p[b + i];
-    }
+    const uint32_t k = (uint32_t)srt[b + i];
+    srt[b + i] = ((uint64_t)k << 32) | (uint32_t)o2p[b + i];
     kor |= k;
     kand &= k;
   }
@@ -121,24 +111,13 @@ __device__ void tile_radix_sort_global(uint64_t* srt, int32_t* o2p, uint64_t* al
   kor = 0u; kand = 0xffffffffu;
 #pragma unroll
   for (int w = 0; w < TS_WAVES; ++w) { kor |= sh.red[w]; kand &= sh.red[TS_WAVES + w]; }
-  uint64_t vary = (uint64_t)(kor ^ kand) << 32;        // bits that differ somewhere in the run
-  if (packed) {
-    ior = ts_wave_or(ior);
-    iand = ts_wave_and(iand);
-    __syncthreads();
-    if (lane == 0) { sh.red[wave] = ior; sh.red[TS_WAVES + wave] = iand; }
-    __syncthreads();
-    ior = 0u; iand = 0xffffffffu;
-#pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) { ior |= sh.red[w]; iand &= sh.red[TS_WAVES + w]; }
-    vary |= (uint64_t)(ior ^ iand);
-  }
+  const uint32_t vary = kor ^ kand;                    // bits that differ somewhere in the run
 
   uint64_t* src = srt;
   uint64_t* dst = alt;
-  for (int pass = packed ? 0 : 4; pass < 8; ++pass) {
-    if (((vary >> (8 * pass)) & 0xffull) == 0ull) continue;     // same digit everywhere: identity permutation
-    const int shift = 8 * pass;
+  for (int pass = 0; pass < 4; ++pass) {
+    if (((vary >> (8 * pass)) & 0xffu) == 0u) continue;         // same digit everywhere: identity permutation
+    const int shift = 32 + 8 * pass;
     __syncthreads();
     sh.hist[t] = 0u;
     __syncthreads();
@@ -196,7 +175,7 @@ __device__ void tile_radix_sort_global(uint64_t* srt, int32_t* o2p, uint64_t* al
     uint64_t* const swap = src; src = dst; dst = swap;
   }
   __syncthreads();
-  if (src == srt && vary == 0ull && !packed) return;             // nothing moved
+  if (src == srt && vary == 0u) return;                          // nothing moved
   for (int i = t; i < n; i += TS_THREADS) o2p[b + i] = (int32_t)(uint32_t)src[b + i];
 }
 
@@ -213,8 +192,7 @@ struct BucketMap {
 };
 
 // false: declined (nothing written) — the keys pile up in few buckets and the run belongs to the bounded path
-// PACKED: srt[b .. b + n) holds depth key << 32 | point index in any order (the tile-bins mapper) and o2p is output only
-template <int R, bool PACKED>
+template <int R>
 __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
                                                  int64_t b, int n, uint64_t* pairs, uint32_t* cnt, TsShared& sh) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -225,14 +203,8 @@ __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int
     const int i = t + TS_THREADS * r;
     key[r] = 0u; id[r] = 0u;
     if (i < n) {
-      if (PACKED) {
-        const uint64_t p = srt[b + i];
-        key[r] = (uint32_t)(p >> 32);
-        id[r] = (uint32_t)p;
-      } else {
-        key[r] = (uint32_t)srt[b + i];
-        id[r] = (uint32_t)o2p[b + i];
-      }
+      key[r] = (uint32_t)srt[b + i];
+      id[r] = (uint32_t)o2p[b + i];
       kmin = key[r] < kmin ? key[r] : kmin;
       kmax = key[r] > kmax ? key[r] : kmax;
     }
@@ -246,33 +218,7 @@ __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int
     kmin = sh.red[w] < kmin ? sh.red[w] : kmin;
     kmax = sh.red[TS_WAVES + w] > kmax ? sh.red[TS_WAVES + w] : kmax;
   }
-  if (kmin == kmax) {
-    if (!PACKED) return true;              // one depth key: the run is in point order already
-    // one depth key, point indices in any order: the indices (all different) are the keys of this run
-    __syncthreads();
-    kmin = 0xffffffffu; kmax = 0u;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (t + TS_THREADS * r < n) {
-        key[r] = id[r];
-        kmin = key[r] < kmin ? key[r] : kmin;
-        kmax = key[r] > kmax ? key[r] : kmax;
-      }
-    }
-    kmin = ts_wave_min(kmin);
-    kmax = ts_wave_max(kmax);
-    if (lane == 0) { sh.red[wave] = kmin; sh.red[TS_WAVES + wave] = kmax; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) {
-      kmin = sh.red[w] < kmin ? sh.red[w] : kmin;
-      kmax = sh.red[TS_WAVES + w] > kmax ? sh.red[TS_WAVES + w] : kmax;
-    }
-    if (kmin == kmax) {                    // a single entry
-      if (t == 0) o2p[b] = (int32_t)kmin;
-      return true;
-    }
-  }
+  if (kmin == kmax) return true;           // one depth key: the run is in point order already
 
   const uint32_t nb = (uint32_t)n;
   BucketMap bucket;
@@ -339,7 +285,7 @@ __device__ __forceinline__ bool tile_bucket_sort(uint64_t* __restrict__ srt, int
 
 // One workgroup per tile (runs of lo < n <= hi <= 256 * R entries; the others belong to the kernel below).  Leaves
 // alt[b] = TS_DECLINED for a run it does not sort, 0 otherwise.
-template <int R, bool PACKED>
+template <int R>
 __global__ void __launch_bounds__(TS_THREADS, R <= 4 ? 8 : 1)
 tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict__ srt, int32_t* __restrict__ o2p,
                        uint64_t* __restrict__ alt, int lo, int hi, int32_t* __restrict__ run_stats) {
@@ -350,8 +296,8 @@ tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict_
   const int64_t tile = blockIdx.x;
   const int64_t b = ranges[2 * tile];
   const int n = ranges[2 * tile + 1] - (int32_t)b;
-  if (n <= lo || n > hi) return;           // lo >= 1: a single entry is sorted (PACKED: lo = 0, it has to be unpacked)
-  const bool sorted = tile_bucket_sort<R, PACKED>(srt, o2p, b, n, pairs, cnt, sh);
+  if (n <= lo || n > hi) return;           // lo >= 1: a single entry is sorted
+  const bool sorted = tile_bucket_sort<R>(srt, o2p, b, n, pairs, cnt, sh);
   if (threadIdx.x == 0) {
     alt[b] = sorted ? 0ull : TS_DECLINED;
     if (!sorted && run_stats) atomicOr(run_stats + 2, 1);          // tells the long-run kernel to look for the marks
@@ -361,7 +307,7 @@ tile_depth_sort_kernel(const int32_t* __restrict__ ranges, uint64_t* __restrict_
 // The long runs (n > lo) and the declined ones: 60 KB of LDS per workgroup, so the grid is a few workgroups per CU and
 // each takes a contiguous share of the tiles — one thread looks at one tile's run, the workgroup then sorts the ones
 // that are its business: in LDS up to 256 * R entries, by the bounded path beyond (or when declined).
-template <int R, bool PACKED>
+template <int R>
 __global__ void __launch_bounds__(TS_THREADS)
 tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tiles, uint64_t* __restrict__ srt,
                             int32_t* __restrict__ o2p, uint64_t* __restrict__ alt, int lo, int32_t* __restrict__ run_stats,
@@ -401,43 +347,31 @@ tile_depth_sort_long_kernel(const int32_t* __restrict__ ranges, int64_t num_tile
       const int64_t b = ranges[2 * tile];
       const int n = ranges[2 * tile + 1] - (int32_t)b;
       bool sorted = false;
-      if (n <= CAP && !(entry >> 30)) sorted = tile_bucket_sort<R, PACKED>(srt, o2p, b, n, pairs, cnt, sh);
+      if (n <= CAP && !(entry >> 30)) sorted = tile_bucket_sort<R>(srt, o2p, b, n, pairs, cnt, sh);
       if (!sorted) {
         __syncthreads();
-        tile_radix_sort_global(srt, o2p, alt, b, n, sh, cnt, PACKED);
+        tile_radix_sort_global(srt, o2p, alt, b, n, sh, cnt);
       }
       __syncthreads();                     // done with the shared arrays before the next run
     }
   }
 }
 
-template <bool PACKED>
-static void tile_depth_sort_launch_t(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
-                                     uint64_t* scratch, hipStream_t s, int32_t* run_stats, int32_t* run_host) {
+void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
+                            uint64_t* scratch, hipStream_t s, int32_t* run_stats, int32_t* run_host) {
   if (num_tiles <= 0) return;
   const dim3 per_tile((unsigned)num_tiles), block(TS_THREADS);
   int covered = TS_THREADS * TS_SMALL_R;
-  tile_depth_sort_kernel<TS_SMALL_R, PACKED><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch,
-                                                                        PACKED ? 0 : 1, covered, run_stats);
+  tile_depth_sort_kernel<TS_SMALL_R><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, 1, covered,
+                                                                run_stats);
 #if TS_MID_R > 0
-  tile_depth_sort_kernel<TS_MID_R, PACKED><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, covered,
-                                                                     TS_THREADS * TS_MID_R, run_stats);
+  tile_depth_sort_kernel<TS_MID_R><<<per_tile, block, 0, s>>>(tile_ranges, sorted_keys, overlap_to_point, scratch, covered,
+                                                             TS_THREADS * TS_MID_R, run_stats);
   covered = TS_THREADS * TS_MID_R;
 #endif
   const int64_t few = 2 * 256;             // two workgroups of the long-run kernel fit a CU
-  tile_depth_sort_long_kernel<TS_LONG_R, PACKED><<<dim3((unsigned)(num_tiles < few ? num_tiles : few)), block, 0, s>>>(
+  tile_depth_sort_long_kernel<TS_LONG_R><<<dim3((unsigned)(num_tiles < few ? num_tiles : few)), block, 0, s>>>(
       tile_ranges, num_tiles, sorted_keys, overlap_to_point, scratch, covered, run_stats, run_host);
-}
-
-void tile_depth_sort_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* sorted_keys, int32_t* overlap_to_point,
-                            uint64_t* scratch, hipStream_t s, int32_t* run_stats, int32_t* run_host) {
-  tile_depth_sort_launch_t<false>(tile_ranges, num_tiles, sorted_keys, overlap_to_point, scratch, s, run_stats, run_host);
-}
-
-// pairs (K): depth key << 32 | point index, grouped by tile (tile_ranges) in ANY order inside a run
-void tile_depth_sort_pairs_launch(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* pairs, int32_t* overlap_to_point,
-                                  uint64_t* scratch, hipStream_t s, int32_t* run_stats, int32_t* run_host) {
-  tile_depth_sort_launch_t<true>(tile_ranges, num_tiles, pairs, overlap_to_point, scratch, s, run_stats, run_host);
 }
 
 }  // namespace ms
@@ -450,16 +384,6 @@ extern "C" int ms_tile_depth_sort(const int32_t* tile_ranges, int64_t num_tiles,
   if (num_tiles == 0) return 0;
   MS_CHECK_ARG(tile_ranges && sorted_keys && overlap_to_point && scratch, "null pointer");
   tile_depth_sort_launch(tile_ranges, num_tiles, sorted_keys, overlap_to_point, scratch, (hipStream_t)stream);
-  MS_CHECK_LAUNCH();
-  return 0;
-}
-
-extern "C" int ms_tile_depth_sort_pairs(const int32_t* tile_ranges, int64_t num_tiles, uint64_t* pairs,
-                                        int32_t* overlap_to_point, uint64_t* scratch, void* stream) {
-  MS_CHECK_ARG(num_tiles >= 0 && num_tiles < (1ll << 31), "num_tiles out of range");
-  if (num_tiles == 0) return 0;
-  MS_CHECK_ARG(tile_ranges && pairs && overlap_to_point && scratch, "null pointer");
-  tile_depth_sort_pairs_launch(tile_ranges, num_tiles, pairs, overlap_to_point, scratch, (hipStream_t)stream, nullptr, nullptr);
   MS_CHECK_LAUNCH();
   return 0;
 }

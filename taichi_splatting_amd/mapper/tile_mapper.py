@@ -41,9 +41,8 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
                        method: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor]:
   """``map_to_tiles`` restricted to tile rows [tile_rows[0], tile_rows[1]) (multi-GPU strips).
 
-  ``method``: ``'direct'`` (storage-order emission, stable sort on the tile bits, per-tile depth sort),
-  ``'presort'`` (gaussians sorted by depth first, overlaps sorted by tile id) or ``'bins'`` (per-tile counts, slots of a
-  tile's run claimed with atomics, per-tile sort of depth key | point pairs) — three constructions of the SAME lists
+  ``method``: ``'direct'`` (storage-order emission, stable sort on the tile bits, per-tile depth sort) or
+  ``'presort'`` (gaussians sorted by depth first, overlaps sorted by tile id) — two constructions of the SAME lists
   (tile, depth key, point index); ``None`` picks by overlaps per gaussian (``PRESORT_ABOVE``), which is known here
   before anything is emitted.  ``'direct'`` sorts a tile run beyond 5120 entries with one workgroup (~12 ns per entry):
   pass ``method='presort'`` for scenes that pile tens of thousands of splats on one tile (the frame executor notices
@@ -117,40 +116,6 @@ def map_to_tiles_strip(gaussians: torch.Tensor, depth: torch.Tensor,
         raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
                             "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
       return total
-
-    if method == 'bins':
-      # counting sort on the tile id (round 6): 1. overlaps counted PER TILE; 2. their exclusive scan is tile_ranges and
-      # the total (the host sync); 3. every overlap claims a slot of its tile's run and writes depth key << 32 | point;
-      # 4. each run sorted on the 64 bit pairs (all different: the order the claims happened in does not matter)
-      tile_counts = torch.zeros((num_tiles,), dtype=torch.int32, device=device)
-      _lib.check(lib.ms_tile_histogram(points.data_ptr(), v, w_pad, h_pad, tile_size, config.alpha_threshold, row_begin,
-                                       row_end, tile_counts.data_ptr(), stream), "map_to_tiles")
-      cursor = torch.empty((num_tiles + 1,), dtype=torch.int32, device=device)
-      nbytes = ctypes.c_size_t(0)
-      _lib.check(lib.ms_exclusive_scan_i32(None, num_tiles, None, None, None, ctypes.byref(nbytes), stream), "map_to_tiles")
-      tmp = scratch(nbytes.value)
-      _lib.check(lib.ms_exclusive_scan_i32(tile_counts.data_ptr(), num_tiles, cursor.data_ptr(), None, tmp.data_ptr(),
-                                           ctypes.byref(nbytes), stream), "map_to_tiles")
-      total = int(cursor[num_tiles].item())
-      if total < 0:
-        raise OverflowError("map_to_tiles: more than 2^31 - 1 tile overlaps (the overlap index is int32 like the "
-                            "reference's, tile_mapper.py:150); use a larger tile size or fewer / smaller gaussians")
-      if total == 0:
-        return torch.empty((0,), dtype=torch.int32, device=device), tile_ranges.zero_()
-      starts = cursor[:num_tiles].clone()
-      pairs = torch.empty((total,), dtype=torch.int64, device=device)
-      _lib.check(lib.ms_tile_emit_bins(points.data_ptr(), depths.data_ptr(), _lib.dtype_code(depths.dtype), v, w_pad, h_pad,
-                                       tile_size, config.alpha_threshold, row_begin, row_end, int(use_depth16), near, far,
-                                       total, cursor.data_ptr(), pairs.data_ptr(), stream), "map_to_tiles")
-      ends = cursor[:num_tiles]
-      empty = ends == starts                                        # empty tiles are [0, 0) like ms_find_ranges'
-      tile_ranges.view(-1, 2)[:, 0] = torch.where(empty, 0, starts)
-      tile_ranges.view(-1, 2)[:, 1] = torch.where(empty, 0, ends)
-      overlap_to_point = torch.empty((total,), dtype=torch.int32, device=device)
-      alt = torch.empty((total,), dtype=torch.int64, device=device)
-      _lib.check(lib.ms_tile_depth_sort_pairs(tile_ranges.data_ptr(), num_tiles, pairs.data_ptr(),
-                                              overlap_to_point.data_ptr(), alt.data_ptr(), stream), "map_to_tiles")
-      return overlap_to_point, tile_ranges
 
     counts = torch.empty((v,), dtype=torch.int32, device=device)
     cum = total = None
