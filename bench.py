@@ -1052,6 +1052,20 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
     dense()
   out["iteration_ms_dense_step"] = round(timed(dense, steps), 3)
   out["render_backward_ms"] = round(timed(render_backward, steps), 3)
+  # opt-in (frame.VISIBILITY_FROM_BACKWARD): the forward runs without the visibility sums, the backward pass — which visits
+  # every pair again with a lane per splat — writes them; NOT the reference's number exactly (it lacks the pairs behind a
+  # pixel's saturation point, <= 1e-4 per pixel: oracle/raster.py active_visibility), so not the default
+  keep_vis = frame.VISIBILITY_FROM_BACKWARD
+  frame.VISIBILITY_FROM_BACKWARD = True
+  try:
+    for _ in range(2):
+      dense()
+    out["visibility_from_backward"] = {"iteration_ms_dense_step": round(timed(dense, steps), 3),
+                                       "iteration_ms_reference_loop": round(timed(literal, steps), 3),
+                                       "render_backward_ms": round(timed(render_backward, steps), 3),
+                                       "passes_on_demand": frame.visibility_passes}
+  finally:
+    frame.VISIBILITY_FROM_BACKWARD = keep_vis
 
   # the optimiser alone, on the gradients and visibilities of the last frame
   r = render_backward()

@@ -232,6 +232,8 @@ int ms_raster_bwd(const void* points7, const void* features, const int32_t* tile
  *   [6..8]  dL/dfeature = sum w G_c (backward.py:197)
  *   [9..10] with cfg->compute_point_heuristic: sum (dL/dalpha)^2 and sqrt-scaled sum |dL/dmean|_1
  *           (backward.py:190-194)
+ *   [11]    with cfg->compute_point_heuristic: sum of the blend weights w = alpha T of the pairs visited (not the ones
+ *           backward.py:154 drops behind a pixel's saturation point)
  * Every geometric gradient of gaussian_pdf_with_grad (generic.py:321-336) is a per-splat linear map of these
  * sums; ms_raster_moments_finalize applies it once per point and STORES grad_points7 (V,7), grad_features
  * (V,3) and point_heuristic (V,2) (each may be NULL).
@@ -431,6 +433,13 @@ typedef struct ms_frame_grads {
   void *grad_points7, *grad_colours;   /* moments path: optional stores of the summed 2D-boundary gradients */
   void *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit, *grad_feature, *grad_camera;
   void* point_heuristic;           /* (n, 2), written (moments path) or accumulated (zero-initialised) */
+  void* point_visibility;          /* (n,) or NULL.  Moments path with raster.compute_point_heuristic, MS_BACKWARD_ALL: for
+                                      every gaussian that passed the projection's culling, WRITES the sum of the blend weights
+                                      of the (pixel, splat) pairs the raster backward visited: the visibility of
+                                      forward.py:127-128 WITHOUT the pairs behind a pixel's saturation point (backward.py:154
+                                      drops them, the forward keeps adding them: at most 1 - saturate_threshold per pixel).
+                                      A training loop that accepts that difference can run its forward without
+                                      out_visibility.  Ignored on the other paths (ms_frame_uses_moments() tells which runs) */
   int32_t boundary_stride;         /* 0: grad_points7 (n, 7) and grad_colours (n, f) are two dense arrays.  > 0: both are
                                       columns of ONE row-major array with this many floats per row (the return buffer of a
                                       multi-GPU rank step: grad_colours = grad_points7 + 7, stride 7 + f) — float32 frames,

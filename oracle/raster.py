@@ -276,6 +276,39 @@ def near_gate(points, ranges, o2p, image_size, cfg, eps: float, return_counts: b
   return pixel_flag, splat_flag
 
 
+def active_visibility(points, ranges, o2p, image_size, cfg):
+  """Per splat: the sum of its blend weights over the (pixel, splat) pairs the BACKWARD visits — ``forward``'s visibility
+  (forward.py:127-128) without the pairs behind a pixel's saturation point, which backward.py:154,160 drop while the
+  forward keeps adding them (it has no early exit).  What ``ms_frame_grads.point_visibility`` holds
+  (frame.VISIBILITY_FROM_BACKWARD); it is below ``forward``'s visibility by at most 1 - saturate_threshold per pixel."""
+  w, h = image_size
+  ts = cfg.tile_size
+  tiles_wide, tiles_high = _tiles(image_size, ts)
+  dtype = points.dtype
+  visibility = torch.zeros((points.shape[0],), dtype=dtype)
+  ranges = ranges.reshape(-1, 2)
+  for tile_id in range(tiles_wide * tiles_high):
+    start, end = int(ranges[tile_id, 0]), int(ranges[tile_id, 1])
+    if end <= start:
+      continue
+    px, py, inb, pix = _tile_pixels(tile_id, tiles_wide, ts, w, h, dtype)
+    pix = pix[inb]                                  # out-of-bounds pixels start saturated (W = 1)
+    P = pix.shape[0]
+    if P == 0:
+      continue
+    ids = o2p[start:end].long()
+    g = points[ids]
+    a_raw = g[None, :, 6] * pdf(pix, g, cfg.antialias)
+    gate = a_raw > cfg.alpha_threshold
+    a = torch.where(gate, torch.clamp_max(a_raw, cfg.clamp_max_alpha), torch.zeros_like(a_raw))
+    T_incl = torch.cumprod(1 - a, dim=1)
+    T_excl = torch.cat([torch.ones((P, 1), dtype=dtype), T_incl[:, :-1]], dim=1)
+    active = gate & ((1 - T_excl) < cfg.saturate_threshold)       # backward.py:154,160
+    weight = torch.where(active, a, torch.zeros_like(a)) * T_excl
+    visibility.index_add_(0, ids, weight.sum(0))
+  return visibility
+
+
 def saturation_margin(points, ranges, o2p, image_size, cfg):
   """Where the BACKWARD's saturation test can legitimately flip in float32.  backward.py:154,160 drop a (pixel, splat)
   pair once the accumulated weight in front of it reaches ``saturate_threshold``, i.e. once the transmittance T in front

@@ -100,6 +100,7 @@ class FrameGradsC(_SizedStructure):
     ('grad_position', c_void_p), ('grad_log_scaling', c_void_p), ('grad_rotation', c_void_p),
     ('grad_alpha_logit', c_void_p), ('grad_feature', c_void_p), ('grad_camera', c_void_p),
     ('point_heuristic', c_void_p),
+    ('point_visibility', c_void_p),
     ('boundary_stride', c_int32), ('gather_world', c_int32),
     ('gather_rows', c_void_p), ('gather_slots', c_void_p), ('gather_route', c_void_p),
     ('boundary_form', c_int32), ('grad_image_broadcast', c_int32),

@@ -477,6 +477,7 @@ extern "C" int ms_frame_backward(const ms_frame_desc* desc, const ms_frame_input
     a.moments = gr->moments; a.deterministic = gr->deterministic; a.fixed_exp = gr->fixed_exp;
     a.store_points7 = gr->grad_points7; a.store_colours = gr->grad_colours;
     a.point_heuristic = d.raster.compute_point_heuristic ? gr->point_heuristic : nullptr;
+    a.point_visibility = d.raster.compute_point_heuristic ? gr->point_visibility : nullptr;
   } else {
     a.grad_points7 = gr->grad_points7; a.grad_colours = gr->grad_colours;
     a.boundary_stride = gr->boundary_stride;

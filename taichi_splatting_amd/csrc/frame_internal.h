@@ -180,6 +180,7 @@ struct GaussianBwdArgs {
   void* grad_camera;         // 16 values, accumulated
   void *store_points7, *store_colours;   // the summed 2D-boundary gradients (gaussians2d.grad / features.grad)
   void* point_heuristic;     // (n, 2) from the moment rows
+  void* point_visibility;    // (n,) from column 11 of the moment rows (raster backward run with heuristics), or NULL
 };
 int gaussian_bwd_launch(const GaussianBwdArgs& a, hipStream_t s);
 

@@ -52,7 +52,7 @@ template <typename T> struct GaussBwdDev {
   int f;
   const T *camera_position, *colours;
   T *grad_position, *grad_log_scaling, *grad_rotation, *grad_alpha_logit, *grad_feature, *grad_camera;
-  T *store_points7, *store_colours, *point_heuristic;
+  T *store_points7, *store_colours, *point_heuristic, *point_visibility;
 };
 
 // MOM: the 2D-boundary gradients come from the moment rows (float32, RGB); FIXED: rows of 64-bit fixed point.
@@ -94,7 +94,7 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
     T gcov[3] = {T(0), T(0), T(0)};          // MOM: dL/d(a, b, c) of the 2D covariance straight from the moments
     T gf[GB_MAX_F] = {T(0), T(0), T(0), T(0)};
     T dp[3] = {T(0), T(0), T(0)}, dls[3] = {T(0), T(0), T(0)}, dq[4] = {T(0), T(0), T(0), T(0)}, dal = T(0);
-    T heur0 = T(0), heur1 = T(0);
+    T heur0 = T(0), heur1 = T(0), vis_sum = T(0);
 
     if constexpr (MOM && FIXED) {
       struct alignas(16) Pair { long long lo, hi; };
@@ -112,7 +112,8 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
           blk[idx] = Pair{0, 0};                                             // whole lines go back as zeros
           if (pair < 6) {
             flat[row * 12 + 2 * pair] = (float)((double)v.lo * s_main);
-            flat[row * 12 + 2 * pair + 1] = (float)((double)v.hi * (pair == 4 ? s_h0 : s_main));     // value 9: its own unit
+            // value 9: its own unit; value 11 (blend-weight sum, heuristics rows only): units of 2^-32
+            flat[row * 12 + 2 * pair + 1] = (float)((double)v.hi * (pair == 4 ? s_h0 : pair == 5 ? 0x1p-32 : s_main));
           }
         }
       }
@@ -167,6 +168,7 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         gf[0] = (T)r1.z; gf[1] = (T)r1.w; gf[2] = (T)r2.x;
         heur0 = (T)(alpha * alpha * r2.y);          // backward.py:190-194
         heur1 = (T)(r2.z * IS2);
+        vis_sum = (T)r2.w;                          // sum of the blend weights the raster backward visited (heuristics rows)
       } else if (a.gather_world > 0) {
         // the copies of this splat came back in the rows the pack kernel sent them out in: summed in copy order
         const int copies = a.gather_route[i] >> 16;
@@ -253,6 +255,7 @@ gaussian_bwd_kernel(const GaussBwdDev<T> a) {
         a.point_heuristic[i * 2 + 0] = heur0;
         a.point_heuristic[i * 2 + 1] = heur1;
       }
+      if (MOM && a.point_visibility) a.point_visibility[i] = vis_sum;
       if (DEG < 0 && MOM && a.grad_feature)
         _Pragma("unroll") for (int c = 0; c < GB_MAX_F; ++c) if (c < a.f) a.grad_feature[i * a.f + c] = gf[c];
     }
@@ -316,6 +319,7 @@ static int launch_typed(const GaussianBwdArgs& g, hipStream_t s) {
   a.grad_position = (T*)g.grad_position; a.grad_log_scaling = (T*)g.grad_log_scaling; a.grad_rotation = (T*)g.grad_rotation;
   a.grad_alpha_logit = (T*)g.grad_alpha_logit; a.grad_feature = (T*)g.grad_feature; a.grad_camera = (T*)g.grad_camera;
   a.store_points7 = (T*)g.store_points7; a.store_colours = (T*)g.store_colours; a.point_heuristic = (T*)g.point_heuristic;
+  a.point_visibility = (T*)g.point_visibility;
 
   int64_t blocks = div_up(g.n, 256);
   if (g.grad_camera && blocks > 2048) blocks = 2048;      // bounded atomic count for the 16 camera sums

@@ -125,6 +125,7 @@ __device__ unsigned long long* g_scan_phase_rows = nullptr;
 // loss, dL/dC ~ 1e-7, and rounded the squared heuristic term to 0): e_main for the nine sums that are linear in
 // dL/dimage and for split_score, e_h0 for prune_cost's sum of (dL/dalpha)^2.
 constexpr int FIXED_POINT_BITS = 36;      // a commit of magnitude max|dL/dimage| is worth 2^36 units
+constexpr float VISIBILITY_FIXED_UNIT = 4294967296.0f;      // column 11 (sum of blend weights, <= 1 per pixel): units of 2^-32
 __global__ void fixed_point_exponents_kernel(const float* __restrict__ amax, int32_t* __restrict__ out) {
   const float m = *amax;
   int e = 0;
@@ -164,8 +165,12 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   // a batch of ~260 splats puts ~100 on an 8x8 patch):
   //   BATCH / CAP   320 / 112: 1.50    268 / 128: 1.43    256 / 132: 1.51    (3.27 / 3.04 / 3.04 at 4096^2)
   //   with heuristics (11 floats per row)   256 / 104: 1.73    256 / 110: 1.68    320 / 92: 2.23
-  constexpr int CAP = TS == 16 ? (HEUR ? 110 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 24 : MS_T32_CAP) : MS_T8_CAP;
-  constexpr int NACC = HEUR ? 11 : 9;
+  // Round 6: a heuristics row carries a TWELFTH sum, the blend weights w of the pairs this kernel visits — the splat's
+  // visibility (forward.py:127-128) up to the pairs behind a pixel's saturation point, which the backward drops
+  // (backward.py:154) and the forward keeps adding: at most 1 - saturate_threshold per pixel.  What the forward sums with
+  // a transposing wave reduction per four hits is one addition per pixel step here.  Same LDS: CAP 110 -> 102
+  constexpr int CAP = TS == 16 ? (HEUR ? 102 : 128) : (TS == 32) ? (HEUR ? MS_T32_CAP - 32 : MS_T32_CAP) : (HEUR ? MS_T8_CAP - 12 : MS_T8_CAP);
+  constexpr int NACC = HEUR ? 12 : 9;
   constexpr bool GRID_MOMENTS = MS_GRID_MOMENTS != 0;            // see the blend loop
   // largest basis entry (A..D, in units of sqrt(log2 e / 2) / sigma per pixel) a chunk may hold and still use the grid
   // form: 2.5 <=> sigma 0.34 px, where the expansion costs ~3e-5 of the moments' scale (fuzz: tools/fuzz_raster_bwd.py)
@@ -351,7 +356,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
   }
 #endif
   // ---- commit of a pass: ONE 64-byte, line-aligned row of global float atomics per (patch, splat) ----------------
-  // ROWS_PER rows of NACC sums per instruction (7 x 9 = 63 lanes; 5 x 11 with heuristics): the LDS reads sweep
+  // ROWS_PER rows of NACC sums per instruction (7 x 9 = 63 lanes; 5 x 12 with heuristics): the LDS reads sweep
   // the wave's accumulator block linearly and the loop runs pcount / 7 times (16 lanes per row, 9 of them with
   // data, ran pcount / 4 times: 1.45 -> 1.37 ms on config D; the atomics themselves are 0.10 ms of instruction
   // rate + 0.04 ms of misses: 1.33 ms when every row lands in a 16 MB window, 1.21 ms without the commit).
@@ -378,7 +383,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
         const size_t word = (size_t)(uint32_t)point * MOMENT_ROW + k;
         if (rp.deterministic)
           __hip_atomic_fetch_add(reinterpret_cast<long long*>(moments) + word,
-                                 (long long)llrintf(v * (k == 9 ? fixed_h0 : fixed_main)),
+                                 (long long)llrintf(v * (k == 9 ? fixed_h0 : k == 11 ? VISIBILITY_FIXED_UNIT : fixed_main)),
                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else {
 #if MS_COMMIT_ABLATE == 0
@@ -572,7 +577,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           const float Yr[4] = {Y00, Y00 + D, __builtin_fmaf(D, 2.0f, Y00), __builtin_fmaf(D, 3.0f, Y00)};
 
           float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f;
-          float h0 = 0.f, h1 = 0.f;
+          float h0 = 0.f, h1 = 0.f, vs = 0.f;
           // GRID_MOMENTS: the six moments are first taken in the sub-patch's own pixel grid,
           //   n = sum q {1, x, y, x^2, x y, y^2},  x, y in 0..3,
           // where x and y are compile-time constants of the unrolled steps: a pixel row keeps r = sum_x q {1, x, x^2}
@@ -690,6 +695,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                 }
                 a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
                 if (HEUR) {                                           // backward.py:190-194
+                  vs += w[u];                                         // column 11 (see NACC)
                   const float agm = a_st[u] != 0.0f ? ag : 0.0f;
                   h0 = __builtin_fmaf(agm, agm, h0);
                   if (GRID) {
@@ -759,7 +765,7 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
           // this wave's row of the splat: the lanes of a chunk hold distinct splats, chunks run one after the other
           if (valid) {
             float* row = &s_acc[wave][pos][0];
-            const float v[11] = {m0, m1, m2, m3, m4, m5, a0, a1, a2, h0, h1};
+            const float v[12] = {m0, m1, m2, m3, m4, m5, a0, a1, a2, h0, h1, vs};
 #pragma unroll
             for (int k = 0; k < NACC; ++k) row[k] += v[k];
           }

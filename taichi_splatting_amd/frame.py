@@ -84,6 +84,21 @@ STRICT = os.environ.get('MS_STRICT', '0') not in ('', '0')   # graph replays syn
 # by more than K_SLACK between two frames of one shape (a new camera) would get an exception instead of round 5's
 # transparent re-run.  Worth switching on for loops with a slow host and steady overlap totals.
 LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '0') not in ('', '0')
+# Visibility of a frame that WILL be differentiated with point heuristics on, taken from its backward pass (round 6; OPT-IN:
+# MS_VISIBILITY_FROM_BACKWARD=1 or frame.VISIBILITY_FROM_BACKWARD = True).  The raster backward visits every (pixel, splat)
+# pair again with a lane per splat, where the sum of a splat's blend weights is one more addition per pixel step and a
+# twelfth column of the heuristics' moment row; the forward, a lane per pixel, pays a transposing wave reduction per four
+# hits for it (+0.33 ms on config D).  Such a frame runs its forward WITHOUT visibility and the per-gaussian backward pass
+# writes it.  NOT the reference's number exactly, hence off by default: the reference's forward keeps adding the weights of
+# pairs behind a pixel's saturation point (forward.py:127-128 has no early exit), its backward — and therefore this sum —
+# drops them (backward.py:154); a pixel contributes at most 1 - saturate_threshold = 1e-4 in total to all the splats behind
+# that point (config D-like scenes: 3 % of the gaussians differ by more than 1e-4, the largest difference 1.5e-3; a
+# gaussian wholly behind saturated pixels reads 0 instead of ~1e-5 and counts as invisible).  oracle/raster.py
+# active_visibility() is the quantity, tests/test_gpu_round6.py holds it.  Reading the visibility BEFORE backward()
+# (``rendering.points``, ``point_outputs``) runs the forward's visibility kernel on demand (``visibility_passes``) and gives
+# the reference's number.
+VISIBILITY_FROM_BACKWARD = os.environ.get('MS_VISIBILITY_FROM_BACKWARD', '0') not in ('', '0')
+visibility_passes = 0     # deferred frames whose visibility was read before their backward pass had written it
 LAZY_AFTER = 3
 _stable_frames = {}       # scene-shape key -> settled frames in a row that fitted the remembered capacity
 _unsettled = collections.deque()   # FrameStates whose overlap total the host has not looked at yet (oldest first)
@@ -390,6 +405,35 @@ class FrameState:
     self.captured = False         # enqueued under HIP-graph capture: k_word / k_view = the pinned word replays write K to
     self.k_word = self.k_view = None
     self.overflowed = 0           # largest overlap total a replay was seen to exceed the capacity with (sticky)
+    self.vis_deferred = False     # the forward ran without visibility: the backward writes it (VISIBILITY_FROM_BACKWARD)
+    self.vis_ready = True
+    self.vis_args = None          # what the on-demand pass needs (detached views: no cycle through the autograd node)
+
+  def ensure_visibility(self):
+    """A deferred visibility (VISIBILITY_FROM_BACKWARD) that is read before the backward pass wrote it: the forward's
+    visibility kernel on the frame's kept lists, into a scratch image."""
+    global visibility_passes
+    if not self.vis_deferred or self.vis_ready:
+      return
+    visibility, points7, colours, w, h, f, rows, y0, y1, config = self.vis_args
+    self.settle()
+    self.vis_ready = True
+    visibility_passes += 1
+    if y1 <= y0 or points7.shape[0] == 0 or self.capacity == 0 or self.keep_k is None:
+      return
+    lib = _lib.load()
+    dtype, device = points7.dtype, points7.device
+    cfg_v = _lib.raster_config_c(replace(config, compute_visibility=True, compute_point_heuristic=False))
+    es = points7.element_size()
+    with torch.no_grad():
+      image = torch.empty((y1 - y0, w, f), dtype=dtype, device=device)
+      alpha = torch.empty((y1 - y0, w), dtype=dtype, device=device)
+      visibility.zero_()
+      _lib.check(lib.ms_raster_fwd(points7.data_ptr(), colours.data_ptr(), self.tile_ranges().data_ptr(),
+                                   self.overlap_to_point().data_ptr(), w, h, f, cfg_v,
+                                   image.data_ptr() - y0 * w * f * es, alpha.data_ptr() - y0 * w * es, visibility.data_ptr(),
+                                   rows[0], rows[1], _lib.dtype_code(dtype), _lib.current_stream(device)),
+                 "render_gaussians (visibility on demand)")
 
   def settle(self):
     """Look at the frame's overlap total (waiting for it if the GPU has not produced it yet) and re-run the emission
@@ -708,14 +752,21 @@ class _FrameFunction(torch.autograd.Function):
       # `0 - y0 * ...` would wrap); the raster touches no row, any valid address will do
       state.dummy = torch.empty((16,), dtype=dtype, device=device)
       image_ptr = alpha_ptr = state.dummy.data_ptr()
+    # a frame that will be differentiated may take its visibility from the backward pass (VISIBILITY_FROM_BACKWARD)
+    defer_vis = bool(state.vis_deferred and config.compute_visibility and config.compute_point_heuristic and n > 0
+                     and lib.ms_frame_uses_moments(ctypes.byref(desc), 0))
+    state.vis_deferred, state.vis_ready = defer_vis, not defer_vis
     _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
-                     visibility if config.compute_visibility else None, device,
+                     visibility if config.compute_visibility and not defer_vis else None, device,
                      "render_gaussians", state, settle_now=opts.render_median_depth)
     layout = state.layout
 
     points7 = _view(keep_n, layout.points7, dtype, (n, 7))
     depth = _view(keep_n, layout.depth, dtype, (n,))
     colours = _view(keep_n, layout.colours, dtype, (n, f)) if opts.use_sh else None
+    if defer_vis:
+      state.vis_args = (visibility.detach(), points7.detach(), (colours if opts.use_sh else feat).detach(), w, h, f, rows,
+                        y0, y1, config)
 
     median = None
     if opts.render_median_depth:
@@ -824,6 +875,11 @@ class _FrameFunction(torch.autograd.Function):
     gr.grad_camera = _lib.ptr(grad_camera)
     if config.compute_point_heuristic:
       gr.point_heuristic = ctx.heuristic.data_ptr()
+    vis_here = state.vis_deferred and moments_path and state.vis_args is not None
+    if vis_here:
+      gr.point_visibility = state.vis_args[0].data_ptr()
+    elif state.vis_deferred:
+      state.ensure_visibility()           # (a backward that cannot deliver it: not on the moments path after all)
 
     try:
       with _lock:       # the two launches of a backward pass are enqueued back to back (ctypes releases the GIL)
@@ -832,6 +888,8 @@ class _FrameFunction(torch.autograd.Function):
     except Exception:
       _drop_moments()         # the accumulator rows may have been left half-written: start from a fresh buffer
       raise
+    if vis_here and not state.vis_ready:
+      state.vis_ready = True
 
     if retained:
       # gaussians2d.retain_grad() / features.retain_grad() of the reference's trainers (renderer.py:103-108
@@ -984,6 +1042,7 @@ class LazyPoints:
     state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh = self.args
     n = depth.shape[0]
     state.settle()
+    state.ensure_visibility()
     with torch.no_grad():
       mask = depth > 0
       v = int(mask.sum().item())
@@ -1023,9 +1082,12 @@ def render_frame(gaussians, camera_params, config: RasterConfig, use_sh: bool, u
                       use_sh=bool(use_sh), use_depth16=bool(use_depth16), tile_rows=tile_rows,
                       crop_to_rows=bool(crop_to_rows), render_median_depth=bool(render_median_depth))
   state = FrameState()
-  image, alpha, points7, depth, colours, visibility, heuristic, median = _FrameFunction.apply(
-    *gaussians.shape_tensors(), gaussians.feature, camera_params.T_camera_world.reshape(4, 4),
-    camera_params.projection.reshape(4), opts, state)
+  args = (*gaussians.shape_tensors(), gaussians.feature, camera_params.T_camera_world.reshape(4, 4),
+          camera_params.projection.reshape(4))
+  # (asked for here: inside Function.forward the grad mode is off whatever the caller's is)
+  state.vis_deferred = bool(VISIBILITY_FROM_BACKWARD and config.compute_visibility and config.compute_point_heuristic
+                            and torch.is_grad_enabled() and any(t.requires_grad for t in args))
+  image, alpha, points7, depth, colours, visibility, heuristic, median = _FrameFunction.apply(*args, opts, state)
   points = LazyPoints(state, gaussians, points7, depth, colours, visibility, heuristic, config, use_sh)
   rendering = Rendering(image=image, image_weight=alpha, depth_image=None, median_depth_image=median, points=points,
                         camera=camera_params, config=config)
@@ -1048,7 +1110,8 @@ def point_outputs(rendering) -> dict:
   densification."""
   points = object.__getattribute__(rendering, 'points')
   if hasattr(points, 'args'):
-    _, _, _, depth, _, visibility, heuristic, config, _ = points.args
+    state, _, _, depth, _, visibility, heuristic, config, _ = points.args
+    state.ensure_visibility()
     return {"visibility": visibility if config.compute_visibility else None,
             "point_heuristic": heuristic if config.compute_point_heuristic else None, "depth": depth}
   n = rendering.frame.desc.n if hasattr(rendering, 'frame') else int(points.idx.max()) + 1

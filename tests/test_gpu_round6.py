@@ -528,3 +528,104 @@ def test_first_frame_of_a_shape_maps_with_the_presort_and_carries_the_segments()
     assert torch.equal(first.frame.overlap_to_point()[:first.frame.k], second.frame.overlap_to_point()[:second.frame.k])
   finally:
     frame.release_caches()
+
+
+# ---- visibility of a frame that will be differentiated, from its backward pass (frame.VISIBILITY_FROM_BACKWARD, opt-in) --
+def _vis_frames(cfg, deferred, det=False, read_early=False, n=30000, size=(320, 240)):
+  from taichi_splatting_amd import render_gaussians
+  from taichi_splatting_amd.rasterizer import function as raster_function
+  g, cam = _train_scene(n=n, size=size)
+  g, cam = g.to(DEV), cam.to(device=DEV)
+  g.requires_grad_(True)
+  weight = torch.linspace(0.5, 1.5, size[0] * size[1] * 3, device=DEV).view(size[1], size[0], 3)
+  keep = frame.VISIBILITY_FROM_BACKWARD, raster_function.DETERMINISTIC_BACKWARD
+  frame.VISIBILITY_FROM_BACKWARD, raster_function.DETERMINISTIC_BACKWARD = deferred, det
+  try:
+    r = render_gaussians(g, cam, cfg, use_sh=False)
+    state = r.frame
+    early = frame.point_outputs(r)['visibility'].clone() if read_early else None
+    flags = (state.vis_deferred, state.vis_ready)
+    (r.image * weight).sum().backward()
+    out = frame.point_outputs(r)
+    torch.cuda.synchronize()
+  finally:
+    frame.VISIBILITY_FROM_BACKWARD, raster_function.DETERMINISTIC_BACKWARD = keep
+  return r, g, early, flags, out
+
+
+@pytest.mark.parametrize('tile,det', [(16, False), (8, False), (32, False), (16, True)])
+def test_visibility_written_by_the_backward_pass_vs_oracle(tile, det):
+  """With frame.VISIBILITY_FROM_BACKWARD a frame that will be differentiated with point heuristics on runs its forward
+  WITHOUT the visibility sums; the raster backward adds the blend weights of the pairs it visits as a twelfth column of the
+  heuristics row and the per-gaussian pass writes them: oracle.raster.active_visibility — the reference's visibility minus
+  the pairs behind a pixel's saturation point — in the float-row and in the fixed-point (deterministic) commit.  The
+  default frame's visibility is the oracle's forward's; images, gradients and heuristics are the same either way."""
+  cfg = cfg_for(tile, compute_visibility=True, compute_point_heuristic=True)
+  assert frame.VISIBILITY_FROM_BACKWARD is False                       # opt-in
+  passes = frame.visibility_passes
+  rb, gb, _, flags_b, out_b = _vis_frames(cfg, True, det)
+  rf, gf, _, flags_f, out_f = _vis_frames(cfg, False, det)
+  assert flags_b == (True, False) and rb.frame.vis_ready and flags_f == (False, True)
+  assert frame.visibility_passes == passes                     # read after the backward pass: no pass on demand
+  vis_b, vis_f = out_b['visibility'].cpu().double(), out_f['visibility'].cpu().double()
+  assert int((vis_f > 0).sum()) > 1000
+  assert torch.equal(rb.image, rf.image)
+  assert float((gb.position.grad - gf.position.grad).abs().max()) <= 2e-5 * float(gf.position.grad.abs().max())   # float atomics
+  hb, hf = out_b['point_heuristic'], out_f['point_heuristic']
+  assert float((hb - hf).abs().max()) <= 1e-4 * float(hf.abs().max())
+  # the oracle on the frame's own lists
+  state, _, points7, _, _, _, _, _, _ = object.__getattribute__(rf, 'points').args
+  k = int(state.counters()[0])
+  size = (320, 240)
+  p64 = points7.detach().cpu().double()
+  ranges, o2p = state.tile_ranges().reshape(-1, 2).cpu(), state.overlap_to_point()[:k].cpu()
+  _, alpha_o, vis_o = orast.forward(p64, gf.feature.detach().cpu().double(), ranges, o2p, size, cfg)
+  act_o = orast.active_visibility(p64, ranges, o2p, size, cfg)
+  assert float(alpha_o.max()) > 0.9999                                   # the scene does saturate: the two differ
+  assert float((vis_o - act_o).max()) > 5e-4 and float((vis_o - act_o).min()) >= 0.0
+  tol = lambda want: 2e-5 + 1e-4 * want.abs()
+  # a pair whose saturation test T_before <= 1 - saturate_threshold falls the other way in float32 toggles a weight of
+  # <= alpha 1e-4: saturation_margin says which splats have a pair that close to the line (T is good to ~1e-4 relative
+  # after a tile's few hundred factors); the others must agree like the forward's do
+  margin, _ = orast.saturation_margin(p64, ranges, o2p, size, cfg)
+  # (and the blend gate alpha > alpha_threshold, forward.py:99-101: a pair within float32's reach of it toggles alpha T)
+  firm = (margin > 2e-3) & (orast.gate_margin(p64, ranges, o2p, size, cfg) > 1e-4)
+  assert int(firm.sum()) > 0.8 * firm.numel()
+  err = (vis_b - act_o).abs()
+  assert bool((err[firm] <= tol(act_o[firm])).all()), float(err[firm].max())
+  assert float(err.max()) < 5e-3                                          # a few toggled pixel pairs at most
+  err_f = (vis_f - vis_o).abs()
+  assert bool((err_f[firm] <= tol(vis_o[firm])).all()) and float(err_f.max()) < 5e-3
+
+
+def test_visibility_read_before_the_backward_pass_is_computed_on_demand():
+  """``point_outputs`` / ``rendering.points`` before ``backward()`` on a deferred frame: the forward's visibility kernel
+  runs on the frame's kept lists (counted in frame.visibility_passes) and gives the forward's number.  Frames that will
+  not be differentiated, or run without heuristics, are not deferred at all."""
+  from taichi_splatting_amd import render_gaussians
+  cfg = cfg_for(16, compute_visibility=True, compute_point_heuristic=True)
+  passes = frame.visibility_passes
+  r, g, early, flags, out = _vis_frames(cfg, True, read_early=True)
+  assert flags == (True, True) and frame.visibility_passes == passes + 1
+  _, _, _, _, want = _vis_frames(cfg, False)
+  assert torch.allclose(early, want['visibility'], rtol=1e-4, atol=1e-5)
+  keep = frame.VISIBILITY_FROM_BACKWARD
+  frame.VISIBILITY_FROM_BACKWARD = True
+  try:
+    g3, cam = _train_scene()
+    g3, cam = g3.to(DEV), cam.to(device=DEV)
+    g3.requires_grad_(True)
+    r3 = render_gaussians(g3, cam, cfg, use_sh=False)
+    assert r3.frame.vis_deferred and not r3.frame.vis_ready
+    pts = r3.points
+    assert r3.frame.vis_ready and frame.visibility_passes == passes + 2
+    assert torch.allclose(pts.visibility, want['visibility'][pts.idx], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+      r4 = render_gaussians(g3, cam, cfg, use_sh=False)
+    assert not r4.frame.vis_deferred
+    r5 = render_gaussians(g3, cam, cfg_for(16, compute_visibility=True), use_sh=False)
+    assert not r5.frame.vis_deferred
+    assert torch.allclose(frame.point_outputs(r4)['visibility'], want['visibility'], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(frame.point_outputs(r5)['visibility'], want['visibility'], rtol=1e-4, atol=1e-5)
+  finally:
+    frame.VISIBILITY_FROM_BACKWARD = keep

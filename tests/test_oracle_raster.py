@@ -282,3 +282,32 @@ def test_saturation_margin_known_answers():
   faint = torch.tensor([[4.0, 4.0, 1.0, 0.0, 2.0, 2.0, 0.001]], dtype=torch.float64)
   m, s = orast.saturation_margin(faint, torch.tensor([[0, 1]], dtype=torch.int32), torch.arange(1, dtype=torch.int32), (8, 8), cfg)
   assert math.isinf(m[0].item()) and s[0].item() == 0
+
+
+def test_active_visibility_known_answers():
+  """oracle.raster.active_visibility (round 6): forward visibility without the pairs the backward drops behind a pixel's
+  saturation point.  The four flat splats of the test above (alpha 0.9, T in front 1, 0.1, 0.01, 0.001; 64 pixels; limit
+  0.01): the forward sums 0.9 T over the 64 pixels for each of them, the backward visits the first two everywhere, the
+  third only where the fall-off leaves T above the limit, the fourth nowhere.  Equal to the forward's where nothing
+  saturates."""
+  n = 4
+  p = torch.tensor([[4.0, 4.0, 1.0, 0.0, 400.0, 400.0, 0.9]] * n, dtype=torch.float64)
+  o2p, ranges = one_tile(n)
+  cfg = orast.Cfg(tile_size=8, saturate_threshold=0.99)
+  f = torch.rand(n, 3, dtype=torch.float64)
+  _, _, vis = orast.forward(p, f, ranges, o2p, (8, 8), cfg)
+  act = orast.active_visibility(p, ranges, o2p, (8, 8), cfg)
+  for k, t in enumerate((1.0, 0.1, 0.01, 0.001)):
+    assert abs(vis[k].item() - 64 * 0.9 * t) < 1e-2 * 64 * 0.9 * t
+  assert torch.allclose(act[:2], vis[:2], rtol=1e-12)
+  assert 0.0 <= act[2].item() <= vis[2].item() and act[3].item() == 0.0
+  # the gradients of the colours are the same pairs' weights times dL/dC: with dL/dC = 1 per channel, d f = active visibility
+  img, _, _ = orast.forward(p, f, ranges, o2p, (8, 8), cfg)
+  _, gf, _ = orast.backward(p, f, ranges, o2p, img, torch.ones_like(img), (8, 8), cfg)
+  assert torch.allclose(gf[:, 0], act, rtol=1e-12, atol=1e-15)
+  # nothing saturates: the two visibilities are one
+  cfg2 = orast.Cfg(tile_size=8)
+  q = torch.tensor([[2.0, 3.0, 0.8, 0.6, 1.5, 0.9, 0.5], [5.0, 4.0, 0.6, -0.8, 2.0, 1.0, 0.4]], dtype=torch.float64)
+  o2, r2 = one_tile(2)
+  _, _, v2 = orast.forward(q, torch.rand(2, 3, dtype=torch.float64), r2, o2, (8, 8), cfg2)
+  assert torch.allclose(orast.active_visibility(q, r2, o2, (8, 8), cfg2), v2, rtol=1e-12)
