@@ -696,15 +696,18 @@ raster_bwd_scan_kernel(const float* __restrict__ points, const float* __restrict
                 a0 = __builtin_fmaf(w[u], cur[u].x, a0); a1 = __builtin_fmaf(w[u], cur[u].y, a1); a2 = __builtin_fmaf(w[u], cur[u].z, a2);
                 if (HEUR) {                                           // backward.py:190-194
                   vs += w[u];                                         // column 11 (see NACC)
-                  const float agm = a_st[u] != 0.0f ? ag : 0.0f;
+                  // (d alpha)^2 of the pairs that blend: the mask as a clamped multiply (a_st is 0 or above the blend
+                  // gate), and |q tx| + |q ty| as |q| (|tx| + |ty|) — the absolute values are source modifiers: six VALU
+                  // instructions per pixel where compare / select and two products took ten
+                  const float agm = ag * __builtin_amdgcn_fmed3f(a_st[u] * 0x1p60f, 0.0f, 1.0f);
                   h0 = __builtin_fmaf(agm, agm, h0);
                   if (GRID) {
                     const int x = (i + u) & 3, y = i >> 2;
                     const float bx = y == 0 ? gx0 : __builtin_fmaf(gxy, (float)y, gx0), by = y == 0 ? gy0 : __builtin_fmaf(gyy, (float)y, gy0);
                     const float tx = x == 0 ? bx : __builtin_fmaf(gxx, (float)x, bx), ty = x == 0 ? by : __builtin_fmaf(gxy, (float)x, by);
-                    h1 += fabsf(q_ * tx) + fabsf(q_ * ty);
+                    h1 = __builtin_fmaf(fabsf(q_), fabsf(tx) + fabsf(ty), h1);
                   } else {
-                    h1 += fabsf(__builtin_fmaf(qX, A, qY * C)) + fabsf(__builtin_fmaf(qX, B, qY * D));
+                    h1 = __builtin_fmaf(fabsf(q_), fabsf(__builtin_fmaf(X[u], A, Y[u] * C)) + fabsf(__builtin_fmaf(X[u], B, Y[u] * D)), h1);
                   }
                 }
 #if MS_SCAN_STATS
