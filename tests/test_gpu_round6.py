@@ -629,3 +629,45 @@ def test_visibility_read_before_the_backward_pass_is_computed_on_demand():
     assert torch.allclose(frame.point_outputs(r5)['visibility'], want['visibility'], rtol=1e-4, atol=1e-5)
   finally:
     frame.VISIBILITY_FROM_BACKWARD = keep
+
+
+def test_visibility_from_the_backward_pass_under_hip_graph_capture():
+  """A captured training step with frame.VISIBILITY_FROM_BACKWARD: every replay's backward pass writes the visibility of
+  the frame returned by the capture (same tensor, new values when the parameters moved), no pass on demand, no host wait."""
+  from taichi_splatting_amd import render_gaussians
+  cfg = cfg_for(16, compute_visibility=True, compute_point_heuristic=True)
+  g, cam = _train_scene(n=20000, size=(256, 192))
+  g, cam = g.to(DEV), cam.to(device=DEV)
+  g.requires_grad_(True)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+  keep = frame.VISIBILITY_FROM_BACKWARD
+  frame.VISIBILITY_FROM_BACKWARD = True
+  try:
+    def step():
+      for t in leaves:
+        t.grad = None
+      r = render_gaussians(g, cam, cfg, use_sh=False)
+      r.image.sum().backward()
+      return r
+
+    ref = step()
+    want = frame.point_outputs(ref)['visibility'].clone()
+    del ref
+    graph = frame.FrameGraph(step, warmup=2)
+    passes, syncs = frame.visibility_passes, frame.host_syncs
+    for _ in range(2):
+      r = graph.replay()
+    vis = frame.point_outputs(r)['visibility']
+    torch.cuda.synchronize()
+    assert r.frame.vis_deferred and frame.visibility_passes == passes and frame.host_syncs == syncs
+    assert torch.allclose(vis, want, rtol=1e-5, atol=1e-6) and int((vis > 0).sum()) > 1000
+    with torch.no_grad():
+      g.alpha_logit -= 1.0                       # fainter splats: more of each is seen
+    graph.replay()
+    torch.cuda.synchronize()
+    moved = frame.point_outputs(r)['visibility']
+    assert float((moved - want).abs().max()) > 1e-3
+    eager = step()
+    assert torch.allclose(moved, frame.point_outputs(eager)['visibility'], rtol=1e-5, atol=1e-6)
+  finally:
+    frame.VISIBILITY_FROM_BACKWARD = keep
