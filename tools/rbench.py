@@ -66,6 +66,7 @@ def main():
   p.add_argument('--save', default='')
   p.add_argument('--ref', default='')
   p.add_argument('--tag', default='')
+  p.add_argument('--vis', action='store_true', help='also time the forward with the per-splat visibility sums')
   p.add_argument('--rows', action='store_true', help='gather from a splat-row table (ms_splat_rows_pack, ms_raster_*_rows)')
   args = p.parse_args()
 
@@ -195,6 +196,17 @@ def main():
     return round(sum(tot) / len(tot), 4), round(tot[len(tot) // 2], 4), round(tot[0], 4)
   out["fwd_ms_mean_med_min"] = time_ms(fwd)
   out["bwd_ms_mean_med_min"] = time_ms(bwd, pre=lambda: mom.zero_())
+  if args.vis:
+    from dataclasses import replace
+    cfg_v = _lib.raster_config_c(replace(cfg, compute_visibility=True))
+    vis = torch.zeros((n,), device=dev)
+
+    def fwd_vis():
+      _lib.check(lib.ms_raster_fwd(g2d.data_ptr(), feats.data_ptr(), ranges2.data_ptr(), o2p.data_ptr(), w, h, 3, cfg_v,
+                                   image.data_ptr(), alpha.data_ptr(), vis.data_ptr(), 0, th, _lib.dtype_code(torch.float32),
+                                   stream), "fwd vis")
+    out["fwd_vis_ms_mean_med_min"] = time_ms(fwd_vis, pre=lambda: vis.zero_())
+    out["vis_sum"] = round(float(vis.double().sum()), 3)
   print("RBENCH " + json.dumps(out), flush=True)
 
 
