@@ -1,7 +1,7 @@
 #!/bin/bash
 # final session 2 (fresh counter file in the tree): driver-like bench lines, kernel traces of the frame and of the training
-# iteration, smoke, the other named configurations, the twelve emulations  -> gpurun_out/r06t/
-out=gpurun_out/r06t
+# iteration, smoke, the other named configurations, the twelve emulations  -> gpurun_out/r06f2/
+out=gpurun_out/r06f2
 mkdir -p $out
 cd /root/repo
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
@@ -18,5 +18,5 @@ rm -rf $out/trace $out/train_trace
 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; echo "smoke rc=$?" | tee -a $out/smoke.txt
 bash tools/round_numbers.sh > $out/round_numbers.txt 2>&1
 grep -E "==|timed" $out/round_numbers.txt | cut -c1-200
-bash tools/refresh_emulations.sh r06t > $out/emulations.txt 2>&1
+bash tools/refresh_emulations.sh r06f2 > $out/emulations.txt 2>&1
 cat $out/emulations.txt
