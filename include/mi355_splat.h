@@ -473,6 +473,13 @@ int ms_frame_uses_moments(const ms_frame_desc* desc, int deterministic);
 int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream);
 int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
                            int32_t* k_host, void* k_event, void* stream);
+/* The SH colours of a frame (the second half of ms_frame_project: camera position = inverse(T_camera_world)[:3, 3],
+ * perspective/params.py:78-80, then evaluate_sh_at, indexed_spherical_harmonics.py:119-134, into keep_n) as a call of its
+ * own, so that a caller can enqueue it on ANOTHER stream behind ms_frame_project_count (it reads the depths the projection
+ * wrote) and beside the mapper's launches of ms_frame_map_raster: that call, given ms_frame_inputs.colours_ready_event
+ * (an event recorded behind this one), skips the colours and waits for the event in front of the raster forward.  Frames
+ * with sh_degree >= 0 and their own projection only; not with the splat-row table. */
+int ms_frame_sh_colours(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream);
 int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* scratch_n,
                         void* keep_k, void* scratch_k, void* out_image, void* out_alpha, void* out_visibility,
                         void* stream);

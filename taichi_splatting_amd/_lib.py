@@ -162,6 +162,7 @@ SIGNATURES = {
   'ms_frame_layout_query': (c_int, [POINTER(FrameDescC), POINTER(FrameLayoutC)]),
   'ms_frame_uses_moments': (c_int, [POINTER(FrameDescC), c_int]),
   'ms_frame_project': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p]),
+  'ms_frame_sh_colours': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p]),
   'ms_frame_project_count': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'ms_frame_map_raster': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC)] + [c_void_p] * 8),
   'ms_frame_backward': (c_int, [POINTER(FrameDescC), POINTER(FrameInputsC), c_void_p, c_void_p, POINTER(FrameGradsC), c_void_p]),

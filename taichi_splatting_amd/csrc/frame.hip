@@ -259,6 +259,21 @@ extern "C" int ms_frame_project(const ms_frame_desc* desc, const ms_frame_inputs
   return frame_project_impl(desc, in, keep_n, true, true, stream, "ms_frame_project");
 }
 
+extern "C" int ms_frame_sh_colours(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n, void* stream) {
+  MS_TRY(check_desc(desc, "ms_frame_sh_colours"));
+  MS_TRY(check_inputs(in, "ms_frame_sh_colours"));
+  MS_CHECK_ARG(in && keep_n, "null pointer");
+  const ms_frame_desc& d = *desc;
+  MS_CHECK_ARG(!d.projected_input && d.sh_degree >= 0, "a frame that evaluates SH colours itself");
+  MS_CHECK_ARG(!frame_uses_rows(desc), "the splat-row table is filled on the frame's own stream");
+  if (d.n == 0) return 0;
+  ms_frame_layout L;
+  frame_layout(desc, &L);
+  MS_CHECK_ARG(in->T_camera_world != nullptr, "T_camera_world is null");
+  MS_TRY(ms_camera_position(in->T_camera_world, (char*)keep_n + L.camera_position, d.dtype, stream));
+  return frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_sh_colours");
+}
+
 extern "C" int ms_frame_project_count(const ms_frame_desc* desc, const ms_frame_inputs* in, void* keep_n,
                                       void* scratch_n, int32_t* k_host, void* k_event, void* stream) {
   MS_TRY(check_desc(desc, "ms_frame_project_count"));
@@ -342,9 +357,12 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
   int32_t* counters = (int32_t*)(kn + L.counters);
   int32_t* ranges = (int32_t*)(kn + L.tile_ranges);
   int32_t* o2p = (int32_t*)(kk + L.overlap_to_point);
+  // a frame whose SH colours are evaluated by ms_frame_sh_colours on ANOTHER stream, beside the mapper's launches: this
+  // call then neither evaluates them nor makes the camera position, and waits for the event in front of the raster forward
+  const bool colours_elsewhere = !d.projected_input && d.sh_degree >= 0 && in->colours_ready_event != nullptr;
 
   {
-    const bool want_cam = !d.projected_input && d.sh_degree >= 0 && d.n > 0;
+    const bool want_cam = !d.projected_input && d.sh_degree >= 0 && d.n > 0 && !colours_elsewhere;
     if (want_cam) MS_CHECK_ARG(in->T_camera_world != nullptr, "T_camera_world is null");
     const int64_t words = (int64_t)g.num_tiles * 2;
     const dim3 grid((unsigned)(words > 0 ? div_up(words, 256) : 1)), block(256);
@@ -355,7 +373,7 @@ extern "C" int ms_frame_map_raster(const ms_frame_desc* desc, const ms_frame_inp
       frame_prepare_kernel<float><<<grid, block, 0, s>>>(counters, (int32_t)d.k_capacity, (const float*)in->T_camera_world,
                                                          want_cam ? (float*)(kn + L.camera_position) : nullptr, ranges, words);
   }
-  if (!d.projected_input) MS_TRY(frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_map_raster"));
+  if (!d.projected_input && !colours_elsewhere) MS_TRY(frame_project_impl(desc, in, keep_n, false, true, stream, "ms_frame_map_raster"));
   if (d.n > 0 && d.k_capacity > 0) {
     MS_CHECK_ARG(keep_k && scratch_k, "null overlap buffers");
     int32_t* values = (int32_t*)(sk + L.values);

@@ -98,6 +98,16 @@ LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '0') not in ('', '0')
 # (``rendering.points``, ``point_outputs``) runs the forward's visibility kernel on demand (``visibility_passes``) and gives
 # the reference's number.
 VISIBILITY_FROM_BACKWARD = os.environ.get('MS_VISIBILITY_FROM_BACKWARD', '0') not in ('', '0')
+# The SH colours of a CAPTURED frame on a second stream, beside the mapper (round 6): the colours are not needed before the
+# raster forward, the SH pass streams 1.2 GB at the HBM rate while the mapper's dozen launches (scan, radix passes, ranges,
+# per-tile sort) are short and partly latency bound — side by side they fill each other's gaps.  The frame forks behind
+# ms_frame_project_count (the SH kernel reads the depths for its culling) and joins through
+# ms_frame_inputs.colours_ready_event in front of the raster forward; the graph holds both as edges.  Measured on config
+# D, one box, two runs each: a replayed step 3.012 / 3.026 ms with it against 3.050 / 3.076 without — and an EAGER frame
+# 3.115 / 3.119 against 3.074 / 3.079: between two queues the same two dependencies are barrier packets the host submits,
+# dearer than what the overlap returns.  Hence under capture only.  MS_SH_SIDE_STREAM=0 switches it off (A/B).
+SH_SIDE_STREAM = os.environ.get('MS_SH_SIDE_STREAM', '1') not in ('', '0')
+_side_streams = {}        # device index -> the executor's second stream
 visibility_passes = 0     # deferred frames whose visibility was read before their backward pass had written it
 LAZY_AFTER = 3
 _stable_frames = {}       # scene-shape key -> settled frames in a row that fitted the remembered capacity
@@ -405,6 +415,7 @@ class FrameState:
     self.captured = False         # enqueued under HIP-graph capture: k_word / k_view = the pinned word replays write K to
     self.k_word = self.k_view = None
     self.overflowed = 0           # largest overlap total a replay was seen to exceed the capacity with (sticky)
+    self.colours_ready = None     # event behind the SH pass on the executor's second stream (SH_SIDE_STREAM)
     self.vis_deferred = False     # the forward ran without visibility: the backward writes it (VISIBILITY_FROM_BACKWARD)
     self.vis_ready = True
     self.vis_args = None          # what the on-demand pass needs (detached views: no cycle through the autograd node)
@@ -561,6 +572,18 @@ def _enqueue_forward(desc, inputs, keep_n, scratch_n, key, image_ptr, alpha_ptr,
     raise
   if not capturing:
     k_event.record(torch.cuda.current_stream(device))
+  if (capturing and SH_SIDE_STREAM and desc.sh_degree >= 0 and not desc.projected_input and desc.n > 0
+      and os.environ.get('MS_SPLAT_ROWS', '0') != '1'):
+    main = torch.cuda.current_stream(device)
+    with _lock:
+      side = _side_streams.get(device.index)
+      if side is None:
+        side = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    side.wait_stream(main)                # behind the projection (and the overlap count and scan enqueued with it)
+    _lib.check(lib.ms_frame_sh_colours(ctypes.byref(desc), ctypes.byref(inputs), keep_n.data_ptr(), side.cuda_stream), what)
+    state.colours_ready = torch.cuda.Event()
+    state.colours_ready.record(side)
+    inputs.colours_ready_event = int(state.colours_ready.cuda_event)
 
   def map_raster(cap):
     desc.k_capacity = cap

@@ -671,3 +671,50 @@ def test_visibility_from_the_backward_pass_under_hip_graph_capture():
     assert torch.allclose(moved, frame.point_outputs(eager)['visibility'], rtol=1e-5, atol=1e-6)
   finally:
     frame.VISIBILITY_FROM_BACKWARD = keep
+
+
+def test_captured_frames_evaluate_their_sh_colours_on_a_second_stream():
+  """Under HIP-graph capture the SH pass runs on the executor's second stream, beside the mapper's launches, and the raster
+  forward waits for its event (ms_frame_sh_colours, ms_frame_inputs.colours_ready_event); eager frames keep one stream
+  (between two queues the fork and the join cost more than the overlap returns).  Same image and gradients either way."""
+  from taichi_splatting_amd import render_gaussians
+  from taichi_splatting_amd.testing import random_3d_gaussians, random_camera
+  torch.manual_seed(5)
+  size = (256, 192)
+  cam = random_camera(image_size=size)
+  g = random_3d_gaussians(20000, cam, scale_factor=1.0, alpha_range=(0.1, 0.9))
+  g = g.replace(feature=(torch.rand(20000, 3, 16) - 0.5) * 0.5).to(DEV)
+  cam = cam.to(device=DEV)
+  g.requires_grad_(True)
+  leaves = [g.position, g.log_scaling, g.rotation, g.alpha_logit, g.feature]
+  cfg = RasterConfig()
+
+  def step():
+    for t in leaves:
+      t.grad = None
+    r = render_gaussians(g, cam, cfg, use_sh=True)
+    r.image.sum().backward()
+    return r
+
+  ref = step()
+  assert ref.frame.colours_ready is None                      # eager: one stream
+  ref_image, ref_grads = ref.image.detach().clone(), [t.grad.clone() for t in leaves]
+  del ref
+  results = {}
+  keep = frame.SH_SIDE_STREAM
+  try:
+    for side in (True, False):
+      frame.SH_SIDE_STREAM = side
+      graph = frame.FrameGraph(step, warmup=1)
+      for _ in range(2):
+        r = graph.replay()
+      torch.cuda.synchronize()
+      assert (r.frame.colours_ready is not None) == side
+      results[side] = (r.image.detach().clone(), [t.grad.clone() for t in leaves])
+  finally:
+    frame.SH_SIDE_STREAM = keep
+  for side in (True, False):
+    image, grads = results[side]
+    assert torch.equal(image, ref_image)
+    for got, want in zip(grads, ref_grads):                    # float atomics: arrival order
+      assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
