@@ -1052,6 +1052,14 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
     dense()
   out["iteration_ms_dense_step"] = round(timed(dense, steps), 3)
   out["render_backward_ms"] = round(timed(render_backward, steps), 3)
+  # the dense iteration has no host synchronisation: it can be captured whole (frame + backward + optimiser step) and replayed
+  try:
+    graph = frame.FrameGraph(dense, warmup=2)
+    out["iteration_ms_dense_step_graph_replay"] = round(timed(graph.replay, steps), 3)
+    del graph
+  except Exception as e:                                    # (reported, not fatal: the eager numbers above stand)
+    out["iteration_ms_dense_step_graph_replay"] = None
+    out["graph_replay_error"] = f"{type(e).__name__}: {e}"[:300]
   # opt-in (frame.VISIBILITY_FROM_BACKWARD): the forward runs without the visibility sums, the backward pass — which visits
   # every pair again with a lane per splat — writes them; NOT the reference's number exactly (it lacks the pairs behind a
   # pixel's saturation point, <= 1e-4 per pixel: oracle/raster.py active_visibility), so not the default
@@ -1064,6 +1072,12 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
                                        "iteration_ms_reference_loop": round(timed(literal, steps), 3),
                                        "render_backward_ms": round(timed(render_backward, steps), 3),
                                        "passes_on_demand": frame.visibility_passes}
+    try:
+      graph = frame.FrameGraph(dense, warmup=2)
+      out["visibility_from_backward"]["iteration_ms_dense_step_graph_replay"] = round(timed(graph.replay, steps), 3)
+      del graph
+    except Exception as e:
+      out["visibility_from_backward"]["graph_replay_error"] = f"{type(e).__name__}: {e}"[:300]
   finally:
     frame.VISIBILITY_FROM_BACKWARD = keep_vis
 
