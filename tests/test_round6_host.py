@@ -76,3 +76,23 @@ def test_optimiser_step_refuses_cpu_tensors_and_bad_dense_shapes():
     params.step(indexes=None, visibility=torch.rand(n))
   with pytest.raises(AssertionError, match="shape mismatch"):
     params.step(indexes=torch.arange(4), visibility=torch.rand(5))
+
+
+def test_deferred_visibility_bookkeeping_without_a_device():
+  """frame.VISIBILITY_FROM_BACKWARD is opt-in; a frame state that is not deferred, or whose backward pass has written the
+  sums, never runs the pass on demand (no library call is made here: the early returns)."""
+  assert frame.VISIBILITY_FROM_BACKWARD is False and frame.SH_SIDE_STREAM is True
+  st = frame.FrameState()
+  assert (st.vis_deferred, st.vis_ready, st.vis_args, st.colours_ready) == (False, True, None, None)
+  passes = frame.visibility_passes
+  st.ensure_visibility()                                       # not deferred
+  st.vis_deferred, st.vis_ready = True, True
+  st.ensure_visibility()                                       # deferred and already written by the backward pass
+  assert frame.visibility_passes == passes
+  # the grads struct carries the pointer the per-gaussian pass writes the sums through, and the header agrees on its place
+  # (tests/test_abi.py holds every offset against a C compiler)
+  gr = _lib.FrameGradsC()
+  assert gr.point_visibility is None and gr.struct_size == ctypes.sizeof(_lib.FrameGradsC)
+  names = [f[0] for f in _lib.FrameGradsC._fields_]
+  assert names.index('point_visibility') == names.index('point_heuristic') + 1
+  assert 'ms_frame_sh_colours' in _lib.SIGNATURES
