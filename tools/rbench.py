@@ -66,6 +66,7 @@ def main():
   p.add_argument('--save', default='')
   p.add_argument('--ref', default='')
   p.add_argument('--tag', default='')
+  p.add_argument('--heur', action='store_true', help='backward with the point heuristics (the training configuration)')
   p.add_argument('--vis', action='store_true', help='also time the forward with the per-splat visibility sums')
   p.add_argument('--rows', action='store_true', help='gather from a splat-row table (ms_splat_rows_pack, ms_raster_*_rows)')
   args = p.parse_args()
@@ -75,6 +76,9 @@ def main():
   lib = _lib.load()
   cfg, (w, h), g2d, feats, o2p, ranges2 = build_scene(args, dev)
   n, k = g2d.shape[0], o2p.shape[0]
+  if args.heur:
+    from dataclasses import replace as _replace
+    cfg = _replace(cfg, compute_point_heuristic=True)
   cfg_c = _lib.raster_config_c(cfg)
   stream = _lib.current_stream(dev)
   th = (h + cfg.tile_size - 1) // cfg.tile_size
