@@ -1030,11 +1030,24 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
     r = render_backward()
     params.step(indexes=None, visibility=frame.point_outputs(r)['visibility'])
 
+  initial = {k: v.detach().clone() for k, v in params.tensors.items()}
+
+  def reset():
+    """Every timed phase starts from the SAME scene and optimiser state: the steps move the gaussians (and with them the
+    overlap count and every kernel's time), so phases timed one after the other would not be comparable."""
+    with torch.no_grad():
+      for k, p in params.tensors.items():
+        p.copy_(initial[k])
+      for st in params.optimizer.state.values():
+        for v in st.values():
+          if torch.is_tensor(v):
+            v.zero_()
+
   def timed(fn, k):
+    reset()
     with frame.parked_gc():
-      t_ramp = time.perf_counter()             # (the collection that parks the collector idled the GPU: clocks back up first)
-      while time.perf_counter() - t_ramp < 0.15:
-        fn()
+      for _ in range(40):                      # 0.2 s of the phase's own work: clocks up, and every phase is timed over
+        fn()                                   # steps 41 .. 40 + k from the same start
       torch.cuda.synchronize()
       t0 = time.perf_counter()
       for _ in range(k):
@@ -1081,7 +1094,8 @@ def train_iteration(args, g, cam, steps=10, warmup=4):
   finally:
     frame.VISIBILITY_FROM_BACKWARD = keep_vis
 
-  # the optimiser alone, on the gradients and visibilities of the last frame
+  # the optimiser alone, on the gradients and visibilities of a frame of the initial scene
+  reset()
   r = render_backward()
   vis = frame.point_outputs(r)['visibility'].clone()
   visible = (vis > 1e-8).nonzero().squeeze(1)

@@ -88,7 +88,7 @@ LAZY_SETTLE = os.environ.get('MS_LAZY_SETTLE', '0') not in ('', '0')
 # MS_VISIBILITY_FROM_BACKWARD=1 or frame.VISIBILITY_FROM_BACKWARD = True).  The raster backward visits every (pixel, splat)
 # pair again with a lane per splat, where the sum of a splat's blend weights is one more addition per pixel step and a
 # twelfth column of the heuristics' moment row; the forward, a lane per pixel, pays a transposing wave reduction per four
-# hits for it (+0.33 ms on config D).  Such a frame runs its forward WITHOUT visibility and the per-gaussian backward pass
+# hits for it (+0.175 ms on config D).  Such a frame runs its forward WITHOUT visibility and the per-gaussian backward pass
 # writes it.  NOT the reference's number exactly, hence off by default: the reference's forward keeps adding the weights of
 # pairs behind a pixel's saturation point (forward.py:127-128 has no early exit), its backward — and therefore this sum —
 # drops them (backward.py:154); a pixel contributes at most 1 - saturate_threshold = 1e-4 in total to all the splats behind
