@@ -718,3 +718,26 @@ def test_captured_frames_evaluate_their_sh_colours_on_a_second_stream():
     assert torch.equal(image, ref_image)
     for got, want in zip(grads, ref_grads):                    # float atomics: arrival order
       assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_visibility_from_the_backward_pass_is_the_colour_gradient_of_a_unit_loss():
+  """The twelfth column sums the blend weights of exactly the pairs the colour gradient sums (d f_c = sum w dL/dC_c,
+  backward.py:197): with loss = image.sum() the deferred visibility equals d feature[:, 0] bit for bit — same pairs, same
+  order, same atomics."""
+  from taichi_splatting_amd import render_gaussians
+  cfg = cfg_for(16, compute_visibility=True, compute_point_heuristic=True)
+  g, cam = _train_scene()
+  g, cam = g.to(DEV), cam.to(device=DEV)
+  g.requires_grad_(True)
+  keep = frame.VISIBILITY_FROM_BACKWARD
+  frame.VISIBILITY_FROM_BACKWARD = True
+  try:
+    r = render_gaussians(g, cam, cfg, use_sh=False)
+    r.image.sum().backward()
+    vis = frame.point_outputs(r)['visibility']
+    torch.cuda.synchronize()
+  finally:
+    frame.VISIBILITY_FROM_BACKWARD = keep
+  assert r.frame.vis_deferred and int((vis > 0).sum()) > 1000
+  # (one commit per (patch, splat) carries both columns: whatever order the atomics arrive in, they arrive in it for both)
+  assert torch.equal(vis, g.feature.grad[:, 0])
