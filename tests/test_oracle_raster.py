@@ -311,3 +311,26 @@ def test_active_visibility_known_answers():
   o2, r2 = one_tile(2)
   _, _, v2 = orast.forward(q, torch.rand(2, 3, dtype=torch.float64), r2, o2, (8, 8), cfg2)
   assert torch.allclose(orast.active_visibility(q, r2, o2, (8, 8), cfg2), v2, rtol=1e-12)
+
+
+@pytest.mark.parametrize('tile,seed', [(8, 0), (16, 1)])
+def test_active_visibility_bounds_on_a_saturating_scene(tile, seed):
+  """On a crowded random scene (opaque splats: pixels saturate) the backward's visibility lies below the forward's by no
+  more than (1 - saturate_threshold) per pixel of the tiles the splat is listed in, never above it, and equals the colour
+  gradient of a unit loss (backward.py:197) — the three properties the GPU tests of the opt-in rely on."""
+  torch.manual_seed(seed)
+  size = (48, 40)
+  g = random_2d_gaussians(300, size, scale_factor=3.0, alpha_range=(0.6, 0.99))
+  p, f = project_gaussians2d(g).double(), g.feature.double()
+  o2p, ranges, _ = omap.map_to_tiles(p.numpy().astype(np.float32), g.depths.numpy().astype(np.float32), size, tile, 1.0 / 255.0)
+  o2p, ranges = torch.from_numpy(o2p), torch.from_numpy(ranges)
+  cfg = orast.Cfg(tile_size=tile)
+  img, alpha, vis = orast.forward(p, f, ranges, o2p, size, cfg)
+  act = orast.active_visibility(p, ranges, o2p, size, cfg)
+  assert float(alpha.max()) > cfg.saturate_threshold                      # something does saturate
+  gap = vis - act
+  assert float(gap.min()) >= 0.0 and float(gap.max()) > 0.0
+  # every pixel hands at most 1 - saturate_threshold to the splats behind its saturation point
+  assert float(gap.sum()) <= (1.0 - cfg.saturate_threshold) * size[0] * size[1] * 1.0000001
+  _, gf, _ = orast.backward(p, f, ranges, o2p, img, torch.ones_like(img), size, cfg)
+  assert torch.allclose(gf[:, 0], act, rtol=1e-12, atol=1e-15)
